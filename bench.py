@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the render hot path (forward + analytic backward).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--spheres 32] [--aa 1]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one
+``rrt_render_fwd`` + one ``rrt_render_bwd`` through the C ABI (include/rrt.h)
+with a dense upstream gradient, inputs resident in HBM; for N > 1 the image's
+row bands are sharded over the ranks (one process per GPU, launched by
+``python -m torch.distributed.run``) and every step ends with ONE all-reduce of
+the flat parameter-gradient buffer over RCCL (strong scaling of the fixed
+4096x4096 image, BASELINE.json configs[3]).
+
+Workload: seed 0, 32 random spheres translate(c)*scale(rho),
+Phong with specular, root camera, 4096x4096, antialias_samples=1 (jitter at the
+pixel centre), upstream grad g = 2*(image - fliplr(image0)) computed once
+(match_mirror.py:40,45 loss).
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel,
+timed live with HIP events on the launch stream; ``cpu_baseline`` is the CPU
+oracle (float32 torch, array-at-a-time like the Theano graph) timed on this
+host on a bounded band of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "reversible-raytracer_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+BYTES_PER_PIXEL_FWD = 12       # RGB float32 image write
+BYTES_PER_PIXEL_BWD = 12       # RGB float32 upstream-gradient read
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--spheres", type=int, default=32)
+    ap.add_argument("--aa", type=int, default=1)
+    ap.add_argument("--no-cull", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=256, help="rows of the CPU-baseline band (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+class Job(object):
+    """Direct C-ABI driver (no autograd in the timed region)."""
+
+    def __init__(self, dev, size, spheres, aa, row0, rows, cull):
+        from rrt import _native as N
+        from rrt import synthetic
+        self.N = N
+        self.L = N.lib()
+        w2o, mat, light, kinds = synthetic.random_spheres(spheres, seed=0)
+        self.w2o = torch.tensor(w2o, device=dev)
+        self.mat = torch.tensor(mat, device=dev)
+        self.light = torch.tensor(light, device=dev)
+        self.kinds = torch.tensor(kinds, device=dev)
+        self.cam = torch.tensor([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0], dtype=torch.float32, device=dev)
+        self.S, self.size, self.rows, self.row0 = spheres, size, rows, row0
+        sc = N.RrtScene()
+        sc.S, sc.B = spheres, 1
+        sc.w2o, sc.w2o_bstride = self.w2o.data_ptr(), 0
+        sc.material, sc.material_bstride = self.mat.data_ptr(), 0
+        sc.light, sc.kind = self.light.data_ptr(), self.kinds.data_ptr()
+        self.sc = sc
+
+        def view(flags):
+            vw = N.RrtView()
+            vw.x_dims = vw.y_dims = size
+            vw.antialias_samples = aa
+            vw.row0, vw.rows = row0, rows
+            vw.shader_id, vw.specular, vw.transpose = N.SHADER_PHONG, 1, 1
+            vw.jitter_mode, vw.seed = N.JITTER_CENTER, 0
+            vw.flags = flags | (0 if cull else N.FLAG_NO_CULL)
+            vw.max_depth = 1.0
+            vw.cam, vw.cam_bstride, vw.jitter = self.cam.data_ptr(), 0, None
+            return vw
+        self.v_fwd = view(0)
+        self.v_fwd_reuse = view(N.FLAG_REUSE_SETUP)
+        self.v_bwd = view(N.FLAG_REUSE_SETUP)      # the packed scene of the step's forward is still valid
+        nbytes = self.L.rrt_workspace_bytes(ctypes.byref(sc), ctypes.byref(self.v_fwd))
+        assert nbytes > 0
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.image = torch.empty((rows, size, 3), dtype=torch.float32, device=dev)
+        self.grad = torch.empty_like(self.image)
+        self.flat = torch.zeros(spheres * 12 + spheres * 7 + 6, dtype=torch.float32, device=dev)
+        self.stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def fwd(self, reuse=False):
+        v = self.v_fwd_reuse if reuse else self.v_fwd
+        rc = self.L.rrt_render_fwd(ctypes.byref(self.sc), ctypes.byref(v), self._p(self.image), self._p(self.ws),
+                                   self.ws.numel(), self.stream)
+        self.N.check(rc, "rrt_render_fwd")
+
+    def bwd(self):
+        S = self.S
+        base = self.flat.data_ptr()
+        rc = self.L.rrt_render_bwd(ctypes.byref(self.sc), ctypes.byref(self.v_bwd), self._p(self.grad),
+                                   ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * S * 12),
+                                   ctypes.c_void_p(base + 4 * S * 19), self._p(self.ws), self.ws.numel(), self.stream)
+        self.N.check(rc, "rrt_render_bwd")
+
+
+def cpu_baseline(size, spheres, aa, rows):
+    """The CPU oracle (a float32 op-for-op restatement of the reference's
+    Theano graph + autograd) on a band of `rows` rows of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import rrt_oracle as O
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(spheres, seed=0)
+    row0 = max(0, size // 2 - rows // 2)
+    rows = min(rows, size - row0)
+    G = np.random.RandomState(0).randn(rows, size, 3).astype(np.float32)
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=size, y_dims=size,
+                       antialias_samples=aa, row0=row0, rows=rows, dtype=torch.float32)
+    dt = time.time() - t0
+    return {"value": rows * size * aa / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "rows [%d,%d) of the %dx%d/%d-sphere workload, fwd+bwd, float32 torch-CPU oracle, %.1f s"
+                      % (row0, row0 + rows, size, size, spheres, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path is HIP only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from rrt.dist import band
+    row0, rows = band(args.size, rank, world)
+    job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull)
+
+    # upstream gradient of the match_mirror loss, computed once: g = 2 (image - fliplr(image0))
+    job.fwd()
+    job.grad.copy_(2.0 * (job.image - torch.flip(job.image, dims=[1])))
+    torch.cuda.synchronize()
+
+    def step():
+        job.fwd()
+        job.bwd()
+        if use_dist:
+            dist.all_reduce(job.flat)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    rays = args.size * args.size * args.aa
+    value = rays / (elapsed / args.steps) / 1e6
+
+    # per-kernel durations, HIP events on the launch stream (torch's current stream)
+    roofline = None
+    kernels = None
+    if not args.no_kernel_timing:
+        n = max(20, min(args.steps, 100))
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        job.fwd()
+        torch.cuda.synchronize()
+        for i in range(n):
+            ev[i][0].record()
+            job.fwd(reuse=True)          # k_fwd alone (packed scene reused)
+            ev[i][1].record()
+            job.bwd()                    # memset + k_bwd + k_finalize
+            ev[i][2].record()
+        torch.cuda.synchronize()
+        t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+        t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+        px = rows * args.size
+        kernels = {"k_fwd_us": t_f * 1e6, "bwd_group_us": t_b * 1e6,
+                   "k_fwd_GBs": px * BYTES_PER_PIXEL_FWD / t_f / 1e9,
+                   "bwd_group_GBs": px * BYTES_PER_PIXEL_BWD / t_b / 1e9,
+                   "fwd_plus_bwd_GBs": px * (BYTES_PER_PIXEL_FWD + BYTES_PER_PIXEL_BWD) / (t_f + t_b) / 1e9}
+        dom_fwd = t_f >= t_b
+        ach = kernels["k_fwd_GBs"] if dom_fwd else kernels["bwd_group_GBs"]
+        roofline = {"bound": "hbm", "kernel": "k_fwd" if dom_fwd else "k_bwd", "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_rows > 0:
+            cpu = cpu_baseline(args.size, args.spheres, args.aa, args.cpu_rows)
+        out = {
+            "metric": "Mrays/s fwd+bwd at %dx%d/%d spheres" % (args.size, args.size, args.spheres),
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d random spheres (seed 0), %dx%d, antialias_samples=%d, Phong+specular, "
+                                   "root camera, dense upstream grad; row bands over %d GPU(s)"
+                                   % (args.spheres, args.size, args.size, args.aa, world),
+                       "cull": not args.no_cull, "parallelism": "rowband%d" % world},
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

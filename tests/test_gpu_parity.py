@@ -1,0 +1,349 @@
+"""GPU parity: the HIP path (through the C ABI, via rrt.render) against the
+float64 CPU oracle on the same seeded inputs, plus size-independent properties
+at full BASELINE sizes.
+
+Tolerances (float32 kernel vs float64 oracle), chosen from the float32 noise
+floor of the same formulas measured on the CPU harness (test_device_math.py):
+  * image: |d| <= IMG_TOL on every pixel except at most MAX_FLIP_FRAC of them
+    (silhouette pixels whose hit/miss flips between float32 and float64);
+  * parameter gradients: max|d| <= GRAD_RTOL * max|g| per tensor (the adjoint
+    divides by sqrt(Delta), which amplifies float32 rounding at grazing rays).
+"""
+import numpy as np
+import pytest
+import torch
+
+import rrt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 2e-4
+MAX_FLIP_FRAC = 5e-4
+GRAD_RTOL = 5e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from rrt import _native
+    _native.lib()          # must exist on a GPU box: no silent fallback
+    return torch.device("cuda:0")
+
+
+def hip_render(dev, w2o, mat, light, kinds, grad=None, **kw):
+    import rrt
+    tw = torch.tensor(w2o, device=dev, requires_grad=True)
+    tm = torch.tensor(mat, device=dev, requires_grad=True)
+    tl = torch.tensor(light, device=dev, requires_grad=True)
+    cam = kw.pop("cam", None)
+    if cam is not None:
+        cam = torch.tensor(cam, device=dev)
+    img = rrt.render(tw, tm, tl, kinds, cam, **kw)
+    if grad is None:
+        return img.detach().cpu().double().numpy()
+    g = torch.tensor(np.asarray(grad, dtype=np.float32), device=dev)
+    (img * g).sum().backward()
+    torch.cuda.synchronize()
+    return (img.detach().cpu().double().numpy(), tw.grad.cpu().double().numpy(),
+            tm.grad.cpu().double().numpy(), tl.grad.cpu().double().numpy())
+
+
+def oracle(w2o, mat, light, kinds, grad, *, x_dims, y_dims, antialias_samples, jitter=None, cam=None,
+           shader="phong", specular=True, max_depth=1.0, row0=0, rows=None):
+    sd = None
+    if isinstance(jitter, (int, np.integer)):
+        sd = O.sample_dist_from_uniform(O.hash_u01(jitter, y_dims, x_dims, antialias_samples))
+    elif jitter is not None and not isinstance(jitter, str):
+        sd = np.asarray(jitter)
+    cam_o2w = None
+    if cam is not None:
+        cam_o2w = np.eye(4)
+        cam_o2w[:3, :4] = np.asarray(cam[:12]).reshape(3, 4)
+    img, gw, gm, gl = O.render_and_grads(
+        w2o, mat, light, list(kinds) if kinds is not None else None, grad_image=grad,
+        x_dims=x_dims, y_dims=y_dims, antialias_samples=antialias_samples, shader=shader, specular=specular,
+        max_depth=max_depth, cam_o2w=cam_o2w, sample_dist=sd, row0=row0, rows=rows)
+    return img.numpy(), gw.numpy(), gm.numpy(), gl.numpy()
+
+
+def assert_image_close(a, b, what=""):
+    err = np.abs(a - b).max(-1)
+    bad = int((err > IMG_TOL).sum())
+    allowed = max(2, int(MAX_FLIP_FRAC * err.size))
+    assert bad <= allowed, "%s: %d pixels off by > %g (allowed %d), max %g" % (what, bad, IMG_TOL, allowed, err.max())
+
+
+def assert_grad_close(a, b, what=""):
+    scale = max(np.abs(b).max(), 1e-20)
+    err = np.abs(a - b).max()
+    assert err <= GRAD_RTOL * scale, "%s: max|d|=%g vs scale %g (rel %g)" % (what, err, scale, err / scale)
+
+
+def check_scene(dev, w2o, mat, light, kinds, seed=0, **kw):
+    okw = dict(kw)
+    okw.pop("cull", None)
+    rows = kw.get("rows")
+    n_rows = rows if rows is not None else (kw["x_dims"] if kw.get("cam") is None else kw["y_dims"]) - kw.get("row0", 0)
+    n_cols = kw["y_dims"] if kw.get("cam") is None else kw["x_dims"]
+    G = np.random.RandomState(seed).randn(n_rows, n_cols, 3)
+    hi, hw, hm, hl = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **okw)
+    assert_image_close(hi, oi, "image")
+    assert_grad_close(hw, ow, "g_w2o")
+    assert_grad_close(hm[:, :6], om[:, :6], "g_material")
+    assert_grad_close(hl, ol, "g_light")
+    assert np.isfinite(hm).all()
+    return hi
+
+
+# ---------------------------------------------------------------- configs --
+def test_c1_plumbing_1sphere_64(dev):
+    """BASELINE config 1 geometry: one sphere, 64x64, reference default A=4."""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.one_sphere()
+    check_scene(dev, w2o, mat, light, kinds, x_dims=64, y_dims=64, antialias_samples=4, jitter=11)
+
+
+def test_c2_1sphere_phong_512(dev):
+    """BASELINE config 2: 1 sphere Phong 512x512, fwd + analytic bwd."""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.one_sphere()
+    check_scene(dev, w2o, mat, light, kinds, x_dims=512, y_dims=512, antialias_samples=1)
+
+
+@pytest.mark.parametrize("with_square", [False, True])
+def test_c3_match_mirror(dev, with_square):
+    """BASELINE config 3 scene (match_mirror.py:16-29), 256x256 here (the
+    oracle's array-at-a-time autograd at 1024^2 is minutes; the 1024^2 case is
+    covered by the band test below)."""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.match_mirror(with_square)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=256, y_dims=256, antialias_samples=4, jitter=5)
+
+
+def test_c3_match_mirror_1024_band(dev):
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.match_mirror(True)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=1024, y_dims=1024, antialias_samples=1, row0=400, rows=48)
+
+
+def test_depth_shader(dev):
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.match_mirror(True)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=128, y_dims=128, antialias_samples=2, shader="depth",
+                max_depth=20.0)
+
+
+def test_orbit_camera_no_specular(dev, golden_dir):
+    """orbit_experiments scene (planet_orbit.py:21-39): orbit camera (no net
+    transpose), no specular term; also checked against the reference's own
+    render orbit_dataset.npz[99] (8-bit, unseeded jitter => loose)."""
+    import os
+    from rrt import synthetic
+    fx = np.load(os.path.join(golden_dir, "orbit_sample99.npz"))
+    w2o, mat, light, kinds = synthetic.orbit_scene(fx["target"])
+    for c, y in enumerate((2.5, -2.5)):
+        cam = synthetic.orbit_camera(y)
+        img = check_scene(dev, w2o, mat, light, kinds, x_dims=64, y_dims=64, antialias_samples=4,
+                          specular=False, cam=cam, jitter="center" if c == 0 else 9)
+        if c == 0:
+            q = (img * 255).astype(np.uint8).astype(int)
+            d = np.abs(q - fx["images"][c].astype(int)).max(-1)
+            assert (d <= 2).mean() > 0.98
+
+
+def test_match_mirror_reference_jpeg(dev, golden_dir):
+    """output/0.jpg: the reference's own initial render of match_mirror.py."""
+    import os
+    from rrt import synthetic
+    ref = np.load(os.path.join(golden_dir, "match_mirror_0.npy")).astype(np.float64) / 255.0
+    w2o, mat, light, kinds = synthetic.match_mirror(True)
+    img = hip_render(dev, w2o, mat, light, kinds, x_dims=128, y_dims=128, antialias_samples=4, jitter="center")
+    assert np.abs(img - ref).mean() * 255 <= 3.0
+
+
+def test_random_spheres_32(dev):
+    """32-sphere bench scene at a size the oracle finishes in seconds."""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(32, seed=0)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=192, y_dims=192, antialias_samples=2, jitter=21)
+
+
+def test_explicit_jitter(dev):
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(5, seed=2)
+    n, A = 96, 3
+    U = np.random.RandomState(4).rand(n, n, A, 2).astype(np.float32)
+    sd = O.sample_dist_from_uniform(U)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=A, jitter=sd)
+
+
+def test_ellipsoid_rotate_scale(dev):
+    """optimize_brightness.py:28: translate*rotate*scale (general w2o)."""
+    O2 = O.compose(O.compose(O.translate((.5, .5, 4.)), O.rotate(90., (0., 0., 1.))), O.scale((1., 2., 1.5)))
+    O1 = O.translate((-.5, -.5, 4.))
+    w2o = np.stack([O1[1].numpy()[:3], O2[1].numpy()[:3]]).astype(np.float32)
+    mat = np.array([[0.2, 0.9, 0.4, 0.3, 0.7, 0.5, 50.], [0.87, 0.1, 0.507, 0.3, 0.9, 0.4, 50.]], np.float32)
+    light = np.array([-1., -1., 2., 0.961, 1., 0.87], np.float32)
+    check_scene(dev, w2o, mat, light, np.zeros(2, np.uint8), x_dims=128, y_dims=128, antialias_samples=4, jitter=1)
+
+
+# ------------------------------------------------------------- edge cases --
+def test_empty_scene(dev):
+    w2o = np.zeros((0, 3, 4), np.float32)
+    mat = np.zeros((0, 7), np.float32)
+    light = np.array([0, 0, 1, 1, 1, 1], np.float32)
+    G = np.ones((40, 40, 3))
+    img, gw, gm, gl = hip_render(dev, w2o, mat, light, None, grad=G, x_dims=40, y_dims=40, antialias_samples=2)
+    assert img.shape == (40, 40, 3) and (img == 0).all()
+    assert gw.shape == (0, 3, 4) and (gl == 0).all()
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 65, 130])
+def test_ragged_sizes(dev, n):
+    """sizes that are not multiples of the 64-wide tile / 4-row wave stride"""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.match_mirror(True)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=2, jitter=3)
+
+
+def test_all_miss(dev):
+    """sphere behind a far corner: image all zero, gradients exactly zero"""
+    from rrt import synthetic
+    w2o = synthetic._w2o_translate_scale((50., 50., 1.), .1)[None].astype(np.float32)
+    mat = np.array([[.5, .5, .5, .3, .7, .5, 50.]], np.float32)
+    light = np.array([0, 0, 1, 1, 1, 1], np.float32)
+    G = np.ones((64, 64, 3))
+    img, gw, gm, gl = hip_render(dev, w2o, mat, light, None, grad=G, x_dims=64, y_dims=64, antialias_samples=1)
+    assert (img == 0).all() and (gw == 0).all() and (gm == 0).all() and (gl == 0).all()
+
+
+def test_sphere_behind_camera_wins(dev):
+    """no t>0 test for spheres (shape.py:109-126): a sphere behind the camera
+    yields negative t and wins the depth composite"""
+    from rrt import synthetic
+    w2o = np.stack([synthetic._w2o_translate_scale((0., 0., 4.), 1.),
+                    synthetic._w2o_translate_scale((0., 0., -4.), 1.)]).astype(np.float32)
+    mat = np.array([[.9, .1, .1, .3, .7, .5, 50.], [.1, .9, .1, .3, .7, .5, 50.]], np.float32)
+    light = np.array([-1, -1, 2, 1, 1, 1], np.float32)
+    check_scene(dev, w2o, mat, light, np.zeros(2, np.uint8), x_dims=64, y_dims=64, antialias_samples=1)
+
+
+def test_tie_first_shape_wins(dev):
+    """two identical spheres: strict '<' keeps the first (scene.py:46)"""
+    from rrt import synthetic
+    one = synthetic._w2o_translate_scale((0., 0., 4.), 1.)
+    w2o = np.stack([one, one]).astype(np.float32)
+    mat = np.array([[.9, .1, .1, .3, .7, .5, 50.], [.1, .9, .1, .3, .7, .5, 50.]], np.float32)
+    light = np.array([-1, -1, 2, 1, 1, 1], np.float32)
+    G = np.ones((64, 64, 3))
+    img, gw, gm, gl = hip_render(dev, w2o, mat, light, None, grad=G, x_dims=64, y_dims=64, antialias_samples=1)
+    assert (gm[1] == 0).all() and (gw[1] == 0).all() and np.abs(gm[0]).max() > 0
+    assert img[..., 0].max() > img[..., 1].max()
+
+
+# ---------------------------------------------------- structural properties --
+def test_cull_is_exact(dev):
+    """tile culling must not change a single bit (vs brute force)"""
+    import rrt
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(32, seed=0)
+    a = hip_render(dev, w2o, mat, light, kinds, x_dims=1024, y_dims=1024, antialias_samples=1, cull=True)
+    b = hip_render(dev, w2o, mat, light, kinds, x_dims=1024, y_dims=1024, antialias_samples=1, cull=False)
+    assert np.array_equal(a, b)
+
+
+def test_many_shapes_multiword_mask(dev):
+    """S > 64: more than one 64-bit candidate word"""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(150, seed=7)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=96, y_dims=96, antialias_samples=1)
+
+
+def test_bands_tile_the_image_and_gradients_add(dev):
+    """full 4096x4096 / 32 spheres: the 8 row bands of the multi-GPU split
+    reproduce the single-launch image bit for bit and their parameter
+    gradients sum to the single-launch gradient (linearity of the adjoint)."""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(32, seed=0)
+    n = 4096
+    rs = np.random.RandomState(0)
+    G = rs.randn(n, n, 3).astype(np.float32)
+    full = hip_render(dev, w2o, mat, light, kinds, grad=G, x_dims=n, y_dims=n, antialias_samples=1)
+    acc = [np.zeros_like(full[1]), np.zeros_like(full[2]), np.zeros_like(full[3])]
+    for r in range(8):
+        r0, nr = r * 512, 512
+        part = hip_render(dev, w2o, mat, light, kinds, grad=G[r0:r0 + nr], x_dims=n, y_dims=n, antialias_samples=1,
+                          row0=r0, rows=nr)
+        assert np.array_equal(part[0], full[0][r0:r0 + nr])
+        for k in range(3):
+            acc[k] += part[k + 1]
+    for k in range(3):
+        scale = np.abs(full[k + 1]).max()
+        assert np.abs(acc[k] - full[k + 1]).max() <= 1e-4 * scale
+    # coverage sanity of the bench scene (~25-35 %)
+    cov = (full[0].max(-1) > 0).mean()
+    assert 0.1 < cov < 0.6
+
+
+def test_full_size_band_vs_oracle(dev):
+    """4096x4096 / 32 spheres: a 24-row band against the float64 oracle"""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(32, seed=0)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=4096, y_dims=4096, antialias_samples=1, row0=1900, rows=24)
+
+
+def test_batch_axis(dev):
+    """B scenes in one launch == B separate launches; shared w2o => summed grads"""
+    import rrt
+    from rrt import synthetic
+    rs = np.random.RandomState(3)
+    B, n = 5, 64
+    base_w, mat, light, kinds = synthetic.orbit_scene()
+    w = np.stack([synthetic.orbit_scene((rs.uniform(-9, 9), rs.uniform(-9, 9), 32.))[0] for _ in range(B)])
+    cams = np.stack([synthetic.orbit_camera(2.5 if b % 2 == 0 else -2.5) for b in range(B)])
+    G = rs.randn(B, n, n, 3).astype(np.float32)
+    tw = torch.tensor(w, device=dev, requires_grad=True)
+    tm = torch.tensor(mat, device=dev, requires_grad=True)
+    tl = torch.tensor(light, device=dev, requires_grad=True)
+    img = rrt.render(tw, tm, tl, kinds, torch.tensor(cams, device=dev), x_dims=n, y_dims=n, antialias_samples=2,
+                     specular=False, jitter=2)
+    (img * torch.tensor(G, device=dev)).sum().backward()
+    gm_sum = np.zeros((2, 7))
+    gl_sum = np.zeros(6)
+    for b in range(B):
+        one = hip_render(dev, w[b], mat, light, kinds, grad=G[b], cam=cams[b], x_dims=n, y_dims=n,
+                         antialias_samples=2, specular=False, jitter=2)
+        assert np.array_equal(one[0], img[b].detach().cpu().double().numpy())
+        assert np.abs(one[1] - tw.grad[b].cpu().double().numpy()).max() <= 1e-4 * max(np.abs(one[1]).max(), 1e-20)
+        gm_sum += one[2]
+        gl_sum += one[3]
+    assert np.abs(gm_sum - tm.grad.cpu().double().numpy()).max() <= 1e-4 * np.abs(gm_sum).max()
+    assert np.abs(gl_sum - tl.grad.cpu().double().numpy()).max() <= 1e-4 * np.abs(gl_sum).max()
+
+
+def test_scene_api_gradient_descent(dev):
+    """the reference's driver pattern through the class API: match_mirror.py
+    loss, GDOptimizer, sphere centres move and the loss goes down."""
+    import rrt
+    from rrt import (Camera, GDOptimizer, Light, Material, PhongShader, Scene, Sphere, Square, rotate, shared,
+                     translate)
+    rrt.set_device(dev)
+    c1 = shared(np.asarray([-.5, -.5, 4], dtype="float32"))
+    c2 = shared(np.asarray([.5, .5, 4], dtype="float32"))
+    m1 = Material((0.2, 0.9, 0.4), 0.3, 0.7, 0.5, 50.)
+    m2 = Material((0.87, 0.1, 0.507), 0.3, 0.9, 0.4, 50.)
+
+    def make_scene():
+        objs = [Sphere(translate(c1), m1), Sphere(translate(c2), m2),
+                Square(translate((0, 0, 3)) * rotate(50, [0., 1., 0.]), m2)]
+        return Scene(objs, [Light((-1., -1., 2.), (1., 0.87, 0.961))], Camera(128, 128), PhongShader())
+
+    render = make_scene().build(jitter=17).detach()
+    flipped = torch.flip(render, dims=[1])                   # np.fliplr (match_mirror.py:40)
+    cost = lambda: ((make_scene().build(jitter=17) - flipped) ** 2).sum()
+    train = GDOptimizer().optimize([c1, c2], cost, 0.000008, 0.1)
+    losses = [train() for _ in range(15)]
+    assert losses[-1] < losses[0]
+    assert not torch.equal(c1.detach().cpu(), torch.tensor([-.5, -.5, 4.]))
