@@ -62,9 +62,13 @@ struct KArgs {
   int P;                          // rows per wave tile
   int tiles_x, tiles_y;           // wave tiles per scene
   long long n_tiles;              // B * tiles_y * tiles_x
+  int n_waves;                    // waves of a persistent launch (render kernels)
   const float* ps;                // [B][S][PS_STRIDE]
   const float* hdr;               // [B][HDR_STRIDE]
   const unsigned long long* mask; // [n_tiles][nwords]
+  const unsigned* heavy;          // [n_tiles] tiles with >= 1 candidate shape (first counts[0] entries)
+  const unsigned* empty;          // [n_tiles] tiles with none              (first counts[1] entries)
+  const unsigned* counts;         // [4]
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
@@ -91,8 +95,9 @@ __device__ __forceinline__ Tile decode_tile(const KArgs& a, long long tile) {
 // ------------------------------------------------------------------ setup --
 __global__ void k_setup(int S, int B, const float* w2o, long long w2o_bs, const float* mat, long long mat_bs,
                         const float* light, const uint8_t* kind, const float* cam, long long cam_bs,
-                        float* ps, float* hdr, float* acc) {
+                        float* ps, float* hdr, float* acc, unsigned* counts) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < 4) counts[idx] = 0u;
   if (idx < B * S) {
     int b = idx / S, k = idx - b * S;
     pack_shape<float, float>(w2o + b * w2o_bs + 12 * k, cam + b * cam_bs, mat + b * mat_bs + 7 * k, light,
@@ -106,29 +111,67 @@ __global__ void k_setup(int S, int B, const float* w2o, long long w2o_bs, const 
 // -------------------------------------------------------------------- bin --
 // Candidate shapes per tile: a shape is dropped only when no line through the
 // camera origin inside the tile's direction cone can touch its bounding ball.
-__global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out) {
-  long long tile = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tile >= a.n_tiles) return;
-  Tile t = decode_tile(a, tile);
-  int i0, j0, i1, j1;
-  pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
-  pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
-  Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
-  const float* ps = a.ps + (size_t)t.b * a.S * PS_STRIDE;
+// Also compacts the tile ids into a "has candidates" list and a "none" list
+// (one atomic per wave and list), which the persistent render kernels walk.
+constexpr int BIN_LDS = 1024;   // bounding balls staged per block
+__global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out, unsigned* heavy_out,
+                                             unsigned* empty_out, unsigned* counts) {
+  __shared__ float4 s_cull[BIN_LDS];
+  const long long tile0 = (long long)blockIdx.x * blockDim.x;
+  const long long tile = tile0 + threadIdx.x;
+  const bool valid = tile < a.n_tiles;
   const bool nocull = (a.v.flags & RRT_FLAG_NO_CULL) != 0;
-  for (int w = 0; w < a.nwords; ++w) {
-    unsigned long long m = 0;
-    int kend = min(64, a.S - w * 64);
-    for (int kb = 0; kb < kend; ++kb) {
-      bool c = true;
-      if (!nocull) {
-        float4 cr = *reinterpret_cast<const float4*>(ps + (size_t)(w * 64 + kb) * PS_STRIDE + PS_CULL_C);
-        float cc[3] = {cr.x, cr.y, cr.z};
-        c = cone_may_hit<float>(cone, cc, cr.w);
+  // scenes touched by this block's tiles: [b_first, b_first + nb)
+  const long long per_scene = (long long)a.tiles_x * a.tiles_y;
+  const int b_first = (int)(tile0 / per_scene);
+  const long long last = min(tile0 + (long long)blockDim.x, a.n_tiles) - 1;
+  const int nb = (int)(last / per_scene) - b_first + 1;
+  const bool staged = !nocull && (long long)nb * a.S <= BIN_LDS;
+  if (staged) {
+    for (int idx = threadIdx.x; idx < nb * a.S; idx += blockDim.x)
+      s_cull[idx] = *reinterpret_cast<const float4*>(a.ps + ((size_t)b_first * a.S + idx) * PS_STRIDE + PS_CULL_C);
+  }
+  __syncthreads();
+  bool any = false;
+  if (valid) {
+    Tile t = decode_tile(a, tile);
+    int i0, j0, i1, j1;
+    pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
+    pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
+    Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
+    const float* ps = a.ps + (size_t)t.b * a.S * PS_STRIDE;
+    const float4* lc = s_cull + (size_t)(t.b - b_first) * a.S;
+    for (int w = 0; w < a.nwords; ++w) {
+      unsigned long long m = 0;
+      int kend = min(64, a.S - w * 64);
+      for (int kb = 0; kb < kend; ++kb) {
+        bool c = true;
+        if (!nocull) {
+          int k = w * 64 + kb;
+          float4 cr = staged ? lc[k] : *reinterpret_cast<const float4*>(ps + (size_t)k * PS_STRIDE + PS_CULL_C);
+          float cc[3] = {cr.x, cr.y, cr.z};
+          c = cone_may_hit<float>(cone, cc, cr.w);
+        }
+        m |= (unsigned long long)c << kb;
       }
-      m |= (unsigned long long)c << kb;
+      mask_out[tile * a.nwords + w] = m;
+      any |= (m != 0);
     }
-    mask_out[tile * a.nwords + w] = m;
+  }
+  // wave-aggregated append to the two lists
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long bh = __ballot(valid && any), be = __ballot(valid && !any);
+  unsigned base_h = 0, base_e = 0;
+  if (lane == 0) {
+    if (bh) base_h = atomicAdd(&counts[0], (unsigned)__builtin_popcountll(bh));
+    if (be) base_e = atomicAdd(&counts[1], (unsigned)__builtin_popcountll(be));
+  }
+  base_h = __builtin_amdgcn_readfirstlane(base_h);
+  base_e = __builtin_amdgcn_readfirstlane(base_e);
+  if (valid) {
+    if (any) heavy_out[base_h + __builtin_popcountll(bh & lt)] = (unsigned)tile;
+    else empty_out[base_e + __builtin_popcountll(be & lt)] = (unsigned)tile;
   }
 }
 
@@ -194,35 +237,44 @@ __device__ __forceinline__ void trace_rows(const KArgs& a, cfptr ps, cuptr mk, c
   }
 }
 
+__device__ __forceinline__ int global_wave(int& lane) {
+  lane = threadIdx.x & 63;
+  // provably wave-uniform => SGPR addressing downstream
+  return (int)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+}
+
 // ---------------------------------------------------------------- forward --
-template <int P>
+// Persistent: every wave first walks the tiles that have candidate shapes
+// (long jobs first), then helps zero-filling the tiles that have none.
+template <int P, int SHADER, int SPEC>
 __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
   const ViewK& v = a.v;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform => SGPR addressing
-  const long long tile = (long long)blockIdx.x * WAVES + wave;
-  if (tile >= a.n_tiles) return;                          // whole wave
-  const Tile t = decode_tile(a, tile);
-  cuptr mk = as_const(a.mask) + tile * a.nwords;
-  unsigned long long any = 0;
-  for (int w = 0; w < a.nwords; ++w) any |= mk[w];
+  int lane;
+  const int gw = global_wave(lane);
+  cuptr masks = as_const(a.mask);
+  const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
+  const unsigned n_empty = ((const __attribute__((address_space(4))) unsigned*)a.counts)[1];
+  const __attribute__((address_space(4))) unsigned* heavy = (const __attribute__((address_space(4))) unsigned*)a.heavy;
+  const __attribute__((address_space(4))) unsigned* empty = (const __attribute__((address_space(4))) unsigned*)a.empty;
 
-  float c[P][3];
-#pragma unroll
-  for (int p = 0; p < P; ++p) c[p][0] = c[p][1] = c[p][2] = 0.f;
-
-  if (any) {
+  for (unsigned idx = gw; idx < n_heavy; idx += a.n_waves) {
+    const long long tile = heavy[idx];
+    const Tile t = decode_tile(a, tile);
+    cuptr mk = masks + tile * a.nwords;
     cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
     cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
     const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
     const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
+    float c[P][3];
+#pragma unroll
+    for (int p = 0; p < P; ++p) c[p][0] = c[p][1] = c[p][2] = 0.f;
 #pragma unroll 1
     for (int s = 0; s < v.A; ++s) {
       float d[P][3], tmin[P], nu[P][3];
       int best[P];
       gen_rays<P>(a, t, lane, s, d);
-      trace_rows<P, true>(a, ps, mk, d, best, tmin, nu);
-      if (v.shader == SHADER_DEPTH) {
+      trace_rows<P, SHADER == SHADER_PHONG>(a, ps, mk, d, best, tmin, nu);
+      if (SHADER == SHADER_DEPTH) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (best[p] >= 0) {
@@ -250,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
             for (int p = 0; p < P; ++p) {
               if (best[p] == k) {
                 float x[3];
-                shade_phong<float>(nu[p], colI, ks, kd, ka, sh, powf, v.specular, L, look, x);
+                shade_phong<float>(nu[p], colI, ks, kd, ka, sh, powf, SPEC, L, look, x);
                 c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
               }
             }
@@ -258,15 +310,30 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
         }
       }
     }
-  }
-  // one dwordx3 per lane and row: the wave writes 768 contiguous bytes
-  if (lane < t.ncols) {
+    // one dwordx3 per lane and row: the wave writes 768 contiguous bytes
+    if (lane < t.ncols) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      if (p < t.nrows) {
-        F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
-        F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
-        out[lane] = val;
+      for (int p = 0; p < P; ++p) {
+        if (p < t.nrows) {
+          F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+          F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
+          out[lane] = val;
+        }
+      }
+    }
+  }
+
+  for (unsigned idx = gw; idx < n_empty; idx += a.n_waves) {
+    const long long tile = empty[idx];
+    const Tile t = decode_tile(a, tile);
+    if (lane < t.ncols) {
+      const F3 zero = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (p < t.nrows) {
+          F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+          out[lane] = zero;
+        }
       }
     }
   }
@@ -293,111 +360,131 @@ __device__ __forceinline__ float wave_sum_to_lane63(float x) {
 }
 
 template <int P>
+__device__ __forceinline__ void load_grad_rows(const KArgs& a, const Tile& t, int lane, F3 g[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    g[p].x = g[p].y = g[p].z = 0.f;
+    if (lane < t.ncols && p < t.nrows) {
+      const F3* in = reinterpret_cast<const F3*>(a.grad + (((size_t)t.b * a.v.rows + t.a0 + p) * a.v.ncols + t.b0) * 3);
+      g[p] = in[lane];
+    }
+  }
+}
+
+// Persistent over the tiles that have candidates; tiles without never touch
+// the upstream gradient.  The next tile's gradient rows are requested before
+// the current tile is processed, so HBM latency hides behind the adjoint.
+template <int P, int SHADER, int SPEC>
 __global__ __launch_bounds__(BLOCK) void k_bwd(KArgs a) {
   // wave-private staging: upstream gradient (3) and winner id (1) per (row, lane)
   __shared__ float s_up[WAVES][P][3][64];
   __shared__ int s_best[WAVES][P][64];
   const ViewK& v = a.v;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform => SGPR addressing
-  const long long tile = (long long)blockIdx.x * WAVES + wave;
-  if (tile >= a.n_tiles) return;                          // whole wave
-  cuptr mk = as_const(a.mask) + tile * a.nwords;
-  unsigned long long any = 0;
-  int ncand = 0;
-  for (int w = 0; w < a.nwords; ++w) { unsigned long long m = mk[w]; any |= m; ncand += __builtin_popcountll(m); }
-  if (!any) return;                                       // no shape can be hit: nothing to read, nothing to add
-  const Tile t = decode_tile(a, tile);
+  int lane;
+  const int gw = global_wave(lane);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cuptr masks = as_const(a.mask);
+  const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
+  const __attribute__((address_space(4))) unsigned* heavy = (const __attribute__((address_space(4))) unsigned*)a.heavy;
+  if ((unsigned)gw >= n_heavy) return;
 
-  // request all P gradient rows before doing anything else
-  const bool col_ok = lane < t.ncols;
   F3 g[P];
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    g[p].x = g[p].y = g[p].z = 0.f;
-    if (col_ok && p < t.nrows) {
-      const F3* in = reinterpret_cast<const F3*>(a.grad + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
-      g[p] = in[lane];
-    }
+  {
+    const Tile t0 = decode_tile(a, heavy[gw]);
+    load_grad_rows<P>(a, t0, lane, g);
   }
 
-  cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
-  cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
-  const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
-  const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
-  float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
+  for (unsigned idx = gw; idx < n_heavy; idx += a.n_waves) {
+    const long long tile = heavy[idx];
+    const Tile t = decode_tile(a, tile);
+    cuptr mk = masks + tile * a.nwords;
+    int ncand = 0;
+    for (int w = 0; w < a.nwords; ++w) ncand += __builtin_popcountll(mk[w]);
+    const bool col_ok = lane < t.ncols;
+
+    cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
+    cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
+    const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
+    const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
+    float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
 
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    s_up[wave][p][0][lane] = g[p].x * v.inv_A;
-    s_up[wave][p][1][lane] = g[p].y * v.inv_A;
-    s_up[wave][p][2][lane] = g[p].z * v.inv_A;
-  }
-  const int col = t.b0 + min(lane, t.ncols - 1);
-
-#pragma unroll 1
-  for (int s = 0; s < v.A; ++s) {
-    // phase 1: the winner of every ray (skipped when the tile has one candidate:
-    // the adjoint itself tests the hit)
-    if (ncand == 1) {
-      int k0 = 0;
-      for (int w = 0; w < a.nwords; ++w) { unsigned long long m = mk[w]; if (m) k0 = w * 64 + __builtin_ctzll(m); }
-#pragma unroll
-      for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? k0 : -1;
-    } else {
-      float d[P][3], tmin[P];
-      int best[P];
-      gen_rays<P>(a, t, lane, s, d);
-      trace_rows<P, false>(a, ps, mk, d, best, tmin, nullptr);
-#pragma unroll
-      for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
+    for (int p = 0; p < P; ++p) {
+      s_up[wave][p][0][lane] = g[p].x * v.inv_A;
+      s_up[wave][p][1][lane] = g[p].y * v.inv_A;
+      s_up[wave][p][2][lane] = g[p].z * v.inv_A;
     }
-    // phase 2: wave-uniform walk over the candidate shapes
-    for (int w = 0; w < a.nwords; ++w) {
-      unsigned long long m = mk[w];
-      while (m) {
-        int kb = __builtin_ctzll(m);
-        m &= m - 1;
-        int k = w * 64 + kb;
-        bool mine = false;
-#pragma unroll
-        for (int p = 0; p < P; ++p) mine |= (s_best[wave][p][lane] == k);
-        if (!__ballot(mine)) continue;
-        cfptr q = ps + (size_t)k * PS_STRIDE;
-        float A[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
-        float o[3] = {q[PS_O], q[PS_O + 1], q[PS_O + 2]};
-        float colI[3] = {q[PS_COLI], q[PS_COLI + 1], q[PS_COLI + 2]};
-        float ks = q[PS_KS], kd = q[PS_KD], ka = q[PS_KA], sh = q[PS_SH];
-        int kind = ps_load_int(q[PS_KIND]), powf = ps_load_int(q[PS_POWF]);
-        float acc[ACC_USED];
-#pragma unroll
-        for (int n = 0; n < ACC_USED; ++n) acc[n] = 0.f;
-        bool anyhit = false;
+    // prefetch the next tile's gradient rows
+    if (idx + a.n_waves < n_heavy) {
+      const Tile tn = decode_tile(a, heavy[idx + a.n_waves]);
+      load_grad_rows<P>(a, tn, lane, g);
+    }
+    const int col = t.b0 + min(lane, t.ncols - 1);
+
 #pragma unroll 1
-        for (int p = 0; p < t.nrows; ++p) {
-          if (s_best[wave][p][lane] == k) {
-            int i, j;
-            pixel_to_ray(v, t.a0 + p + v.row0, col, i, j);
-            float sdx, sdy, d[3];
-            sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
-            ray_dir<float>(v, i, j, sdx, sdy, d);
-            float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
-            anyhit |= adjoint_ray<float>(kind, A, o, colI, ks, kd, ka, sh, powf, v.shader, v.specular,
-                                         v.inv_max_depth, L, look, d, up, acc);
+    for (int s = 0; s < v.A; ++s) {
+      // phase 1: the winner of every ray (skipped when the tile has one
+      // candidate: the adjoint itself tests the hit)
+      if (ncand == 1) {
+        int k0 = 0;
+        for (int w = 0; w < a.nwords; ++w) { unsigned long long m = mk[w]; if (m) k0 = w * 64 + __builtin_ctzll(m); }
+#pragma unroll
+        for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? k0 : -1;
+      } else {
+        float d[P][3], tmin[P];
+        int best[P];
+        gen_rays<P>(a, t, lane, s, d);
+        trace_rows<P, false>(a, ps, mk, d, best, tmin, nullptr);
+#pragma unroll
+        for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
+      }
+      // phase 2: wave-uniform walk over the candidate shapes
+      for (int w = 0; w < a.nwords; ++w) {
+        unsigned long long m = mk[w];
+        while (m) {
+          int kb = __builtin_ctzll(m);
+          m &= m - 1;
+          int k = w * 64 + kb;
+          bool mine = false;
+#pragma unroll
+          for (int p = 0; p < P; ++p) mine |= (s_best[wave][p][lane] == k);
+          if (!__ballot(mine)) continue;
+          cfptr q = ps + (size_t)k * PS_STRIDE;
+          float A[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+          float o[3] = {q[PS_O], q[PS_O + 1], q[PS_O + 2]};
+          float colI[3] = {q[PS_COLI], q[PS_COLI + 1], q[PS_COLI + 2]};
+          float ks = q[PS_KS], kd = q[PS_KD], ka = q[PS_KA], sh = q[PS_SH];
+          int kind = ps_load_int(q[PS_KIND]), powf = ps_load_int(q[PS_POWF]);
+          float acc[ACC_USED];
+#pragma unroll
+          for (int n = 0; n < ACC_USED; ++n) acc[n] = 0.f;
+          bool anyhit = false;
+#pragma unroll 1
+          for (int p = 0; p < t.nrows; ++p) {
+            if (s_best[wave][p][lane] == k) {
+              int i, j;
+              pixel_to_ray(v, t.a0 + p + v.row0, col, i, j);
+              float sdx, sdy, d[3];
+              sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
+              ray_dir<float>(v, i, j, sdx, sdy, d);
+              float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
+              anyhit |= adjoint_ray<float>(kind, A, o, colI, ks, kd, ka, sh, powf, SHADER, SPEC, v.inv_max_depth,
+                                           L, look, d, up, acc);
+            }
           }
-        }
-        if (!__ballot(anyhit)) continue;
-        // 22 wave sums -> lane n holds value n -> one 22-lane atomic
-        float mine_val = 0.f;
+          if (!__ballot(anyhit)) continue;
+          // 22 wave sums -> lane n holds value n -> one 22-lane atomic
+          float mine_val = 0.f;
 #pragma unroll
-        for (int n = 0; n < ACC_USED; ++n) {
-          float tot = wave_sum_to_lane63(acc[n]);
-          float bc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
-          mine_val = (lane == n) ? bc : mine_val;
+          for (int n = 0; n < ACC_USED; ++n) {
+            float tot = wave_sum_to_lane63(acc[n]);
+            float bc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
+            mine_val = (lane == n) ? bc : mine_val;
+          }
+          if (lane < ACC_USED)
+            __hip_atomic_fetch_add(acc_scene + (size_t)k * ACC_STRIDE + lane, mine_val, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (lane < ACC_USED)
-          __hip_atomic_fetch_add(acc_scene + (size_t)k * ACC_STRIDE + lane, mine_val, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -471,7 +558,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Geometry {
   int P, ncols, nwords, tiles_x, tiles_y;
   long long n_tiles;
-  size_t ps_off, hdr_off, acc_off, mask_off, total;
+  size_t ps_off, hdr_off, acc_off, counts_off, mask_off, heavy_off, empty_off, total;
 };
 
 // Rows per wave tile.  P = 4 (64x4-pixel tiles) once the launch has enough
@@ -501,8 +588,11 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.ps_off = 0;
   g.hdr_off = g.ps_off + n_shapes * PS_STRIDE * sizeof(float);
   g.acc_off = g.hdr_off + (size_t)s->B * HDR_STRIDE * sizeof(float);
-  g.mask_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
-  g.total = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long) + 16, 16);
+  g.counts_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
+  g.mask_off = g.counts_off + 16;
+  g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
+  g.empty_off = align_up(g.heavy_off + (size_t)g.n_tiles * sizeof(unsigned), 16);
+  g.total = align_up(g.empty_off + (size_t)g.n_tiles * sizeof(unsigned) + 16, 16);
   return g;
 }
 
@@ -523,7 +613,7 @@ int validate(const rrt_scene* s, const rrt_view* v) {
   if (v->jitter_mode == RRT_JITTER_EXPLICIT && !v->jitter) return RRT_ERR_NULL;
   if (v->shader_id == RRT_SHADER_DEPTH && !(v->max_depth != 0.f)) return RRT_ERR_SHAPE;
   long long tiles1 = (long long)((v->transpose ? v->y_dims : v->x_dims) + TILE_W - 1) / TILE_W * v->rows * s->B;
-  if (tiles1 > 0x7fffffffLL * WAVES) return RRT_ERR_SHAPE;
+  if (tiles1 > 0x7fffffffLL) return RRT_ERR_SHAPE;      // tile ids are 32-bit
   return RRT_OK;
 }
 
@@ -551,6 +641,10 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.hdr = (const float*)(base + g.hdr_off);
   a.acc = (float*)(base + g.acc_off);
   a.mask = (const unsigned long long*)(base + g.mask_off);
+  a.heavy = (const unsigned*)(base + g.heavy_off);
+  a.empty = (const unsigned*)(base + g.empty_off);
+  a.counts = (const unsigned*)(base + g.counts_off);
+  a.n_waves = 0;
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
   a.image = nullptr;
   a.grad = nullptr;
@@ -562,16 +656,58 @@ int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStr
   int n = s->B * s->S > s->B ? s->B * s->S : s->B;
   hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, s->S, s->B, s->w2o,
                      (long long)s->w2o_bstride, s->material, (long long)s->material_bstride, s->light, s->kind,
-                     v->cam, (long long)v->cam_bstride, const_cast<float*>(a.ps), const_cast<float*>(a.hdr), a.acc);
+                     v->cam, (long long)v->cam_bstride, const_cast<float*>(a.ps), const_cast<float*>(a.hdr), a.acc,
+                     const_cast<unsigned*>(a.counts));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e);
-  if (a.n_tiles > 0 && a.nwords > 0) {
+  if (a.n_tiles > 0) {
     hipLaunchKernelGGL(k_bin, dim3((unsigned)((a.n_tiles + 255) / 256)), dim3(256), 0, st, a,
-                       const_cast<unsigned long long*>(a.mask));
+                       const_cast<unsigned long long*>(a.mask), const_cast<unsigned*>(a.heavy),
+                       const_cast<unsigned*>(a.empty), const_cast<unsigned*>(a.counts));
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e);
   }
   return RRT_OK;
+}
+
+// Persistent launches: enough workgroups to fill every CU at the kernels'
+// register-limited occupancy, never more than there are tiles.
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
+  long long want = (long long)device_cus() * wgs_per_cu;
+  long long need = (n_tiles + WAVES - 1) / WAVES;
+  return (unsigned)(want < need ? want : need);
+}
+
+template <int P>
+void launch_fwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+}
+
+template <int P>
+void launch_bwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+}
+
+int tuned_wgs(const char* name, int dflt) {
+  const char* e = getenv(name);
+  int x = e ? atoi(e) : 0;
+  return x > 0 ? x : dflt;
 }
 
 }  // namespace
@@ -625,10 +761,11 @@ int rrt_render_fwd(const rrt_scene* s, const rrt_view* v, float* image_out, void
     if (rc != RRT_OK) return rc;
   }
   if (g.n_tiles == 0) return RRT_OK;
-  unsigned blocks = (unsigned)((g.n_tiles + WAVES - 1) / WAVES);
-  if (g.P == 4) hipLaunchKernelGGL(k_fwd<4>, dim3(blocks), dim3(BLOCK), 0, st, a);
-  else if (g.P == 2) hipLaunchKernelGGL(k_fwd<2>, dim3(blocks), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_fwd<1>, dim3(blocks), dim3(BLOCK), 0, st, a);
+  unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_FWD_WGS", 8));
+  a.n_waves = (int)blocks * WAVES;
+  if (g.P == 4) launch_fwd<4>(a, blocks, a.v.shader, a.v.specular, st);
+  else if (g.P == 2) launch_fwd<2>(a, blocks, a.v.shader, a.v.specular, st);
+  else launch_fwd<1>(a, blocks, a.v.shader, a.v.specular, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? RRT_OK : hip_fail(e);
 }
@@ -650,10 +787,11 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
   }
   hipError_t e;
   if (g.n_tiles > 0 && s->S > 0) {
-    unsigned blocks = (unsigned)((g.n_tiles + WAVES - 1) / WAVES);
-    if (g.P == 4) hipLaunchKernelGGL(k_bwd<4>, dim3(blocks), dim3(BLOCK), 0, st, a);
-    else if (g.P == 2) hipLaunchKernelGGL(k_bwd<2>, dim3(blocks), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL(k_bwd<1>, dim3(blocks), dim3(BLOCK), 0, st, a);
+    unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 4));
+    a.n_waves = (int)blocks * WAVES;
+    if (g.P == 4) launch_bwd<4>(a, blocks, a.v.shader, a.v.specular, st);
+    else if (g.P == 2) launch_bwd<2>(a, blocks, a.v.shader, a.v.specular, st);
+    else launch_bwd<1>(a, blocks, a.v.shader, a.v.specular, st);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e);
   }

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(_HERE)
 _REPO = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+LIB_PATH = os.environ.get("RRT_LIB", os.path.join(_HERE, "librrt_hip.so"))   # RRT_LIB: diagnostic builds only
 
 RRT_VERSION = 100
 MAX_SHAPES = 1024
@@ -63,7 +63,9 @@ def build_native(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: SLP-packed v_pk_*_f32 cost 8 issue cycles (= two scalar
+    # ops) plus the v_mov shuffles that feed them -- a net loss in these kernels
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-I", INCLUDE, "-I", CSRC] + srcs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

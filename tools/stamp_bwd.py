@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a k_bwd wave spend its cycles?  Builds a -DRRT_STAMPS
+copy of the library (s_memtime stamps at phase boundaries, written to their own
+buffer), runs the bench workload once and prints per-phase cycle statistics of
+the non-empty tiles.  Read SHARES, not lengths (the stamps' fences forbid
+overlaps the real kernel has).  Run on the GPU box:
+    python tools/stamp_bwd.py [--spheres 32] [--size 4096]
+"""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "reversible-raytracer_amd")
+OUT = os.path.join(REPO, "gpurun_out", "librrt_hip_stamps.so")
+os.makedirs(os.path.dirname(OUT), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+                       "-DRRT_STAMPS", "-I", os.path.join(REPO, "include"), "-I", os.path.join(PKG, "csrc"),
+                       os.path.join(PKG, "csrc", "rrt_kernels.hip"), "-o", OUT])
+os.environ["RRT_LIB"] = OUT
+sys.path.insert(0, PKG)
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--spheres", type=int, default=32)
+ap.add_argument("--size", type=int, default=4096)
+ap.add_argument("--aa", type=int, default=1)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+job = bench.Job(dev, args.size, args.spheres, args.aa, 0, args.size, True)
+job.fwd()
+job.grad.copy_(2.0 * (job.image - torch.flip(job.image, dims=[1])))
+for _ in range(3):
+    job.fwd(); job.bwd()
+torch.cuda.synchronize()
+n_tiles = (args.size // 64) * (args.size // 4)
+stamps = torch.zeros((n_tiles + 64, 8), dtype=torch.int64, device=dev)
+rc = job.L.rrt_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+assert rc == 0, rc
+job.fwd(); job.bwd()
+torch.cuda.synchronize()
+st = stamps.cpu().numpy()[:n_tiles]
+heavy = st[:, 6] != 0
+h = st[heavy].astype(np.float64)
+print("tiles", n_tiles, "non-empty", heavy.sum())
+names = ["0->1 mask load + early-out", "1->2 decode + grad loads + LDS stage", "2->3 phase 1 (winners)",
+         "3->4 adjoint rows", "4->5 DPP reduce + atomic", "5->6 loop exit"]
+tot = h[:, 6] - h[:, 0]
+print("total cycles/wave: median %.0f mean %.0f p90 %.0f" % (np.median(tot), tot.mean(), np.percentile(tot, 90)))
+for i, nm in enumerate(names):
+    a, b = h[:, i], h[:, i + 1]
+    ok = (a != 0) & (b != 0) & (b >= a)
+    d = (b - a)[ok]
+    if len(d):
+        print("  %-40s median %8.0f mean %8.0f  share %5.1f%%  (n=%d)" % (nm, np.median(d), d.mean(),
+                                                                         100 * d.sum() / tot.sum(), len(d)))
+span = st[heavy][:, 6].max() - st[heavy][:, 0].min()
+print("kernel span (first start -> last end of non-empty waves): %d cycles; sum of wave lifetimes / span = %.1f waves"
+      % (span, tot.sum() / span))
