@@ -109,69 +109,116 @@ __global__ void k_setup(int S, int B, const float* w2o, long long w2o_bs, const 
 }
 
 // -------------------------------------------------------------------- bin --
-// Candidate shapes per tile: a shape is dropped only when no line through the
+// Candidate shapes per tile.  A shape is dropped only when no line through the
 // camera origin inside the tile's direction cone can touch its bounding ball.
-// Also compacts the tile ids into a "has candidates" list and a "none" list
-// (one atomic per wave and list), which the persistent render kernels walk.
-constexpr int BIN_LDS = 1024;   // bounding balls staged per block
+// Two levels: a workgroup owns a BIN_RX x BIN_RY block of tiles (about square
+// in pixels); its threads first cull the scene's shapes against the whole
+// region (one shape per lane, ballot-compacted into LDS in list order), then
+// every thread tests its own tile against the survivors only.  Finally the
+// tile ids are appended to the "has candidates" / "none" lists with ONE packed
+// 64-bit atomic per workgroup (a same-address atomic costs ~12 ns, so per-wave
+// appends would serialise into tens of microseconds).
+constexpr int BIN_RX = 4, BIN_RY = 64;          // 4*64 tiles = 256 threads; 256 x 64P pixels
 __global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out, unsigned* heavy_out,
-                                             unsigned* empty_out, unsigned* counts) {
-  __shared__ float4 s_cull[BIN_LDS];
-  const long long tile0 = (long long)blockIdx.x * blockDim.x;
-  const long long tile = tile0 + threadIdx.x;
-  const bool valid = tile < a.n_tiles;
+                                             unsigned* empty_out, unsigned long long* counts) {
+  __shared__ float4 s_ball[RRT_MAX_SHAPES];     // surviving shapes' bounding balls, list order
+  __shared__ unsigned short s_id[RRT_MAX_SHAPES];
+  __shared__ int s_wave_n[4];
+  __shared__ int s_n;
+  __shared__ unsigned s_base[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx_n = (a.tiles_x + BIN_RX - 1) / BIN_RX, by_n = (a.tiles_y + BIN_RY - 1) / BIN_RY;
+  int blk = blockIdx.x;
+  const int bx = blk % bx_n; blk /= bx_n;
+  const int by = blk % by_n;
+  const int b = blk / by_n;
+  const int tx = bx * BIN_RX + (tid & (BIN_RX - 1)), ty = by * BIN_RY + (tid / BIN_RX);
+  const bool valid = tx < a.tiles_x && ty < a.tiles_y;
+  const long long tile = ((long long)b * a.tiles_y + ty) * a.tiles_x + tx;
   const bool nocull = (a.v.flags & RRT_FLAG_NO_CULL) != 0;
-  // scenes touched by this block's tiles: [b_first, b_first + nb)
-  const long long per_scene = (long long)a.tiles_x * a.tiles_y;
-  const int b_first = (int)(tile0 / per_scene);
-  const long long last = min(tile0 + (long long)blockDim.x, a.n_tiles) - 1;
-  const int nb = (int)(last / per_scene) - b_first + 1;
-  const bool staged = !nocull && (long long)nb * a.S <= BIN_LDS;
-  if (staged) {
-    for (int idx = threadIdx.x; idx < nb * a.S; idx += blockDim.x)
-      s_cull[idx] = *reinterpret_cast<const float4*>(a.ps + ((size_t)b_first * a.S + idx) * PS_STRIDE + PS_CULL_C);
+  const float* ps = a.ps + (size_t)b * a.S * PS_STRIDE;
+
+  // level 1: region cone vs every shape
+  Cone<float> region;
+  {
+    int ra0 = by * BIN_RY * a.P, ra1 = min((by + 1) * BIN_RY * a.P, a.v.rows) - 1;
+    int rb0 = bx * BIN_RX * TILE_W, rb1 = min((bx + 1) * BIN_RX * TILE_W, a.v.ncols) - 1;
+    int i0, j0, i1, j1;
+    pixel_to_ray(a.v, ra0 + a.v.row0, rb0, i0, j0);
+    pixel_to_ray(a.v, ra1 + a.v.row0, rb1, i1, j1);
+    region = tile_cone<float>(a.v, i0, i1, j0, j1);
   }
-  __syncthreads();
+  int n = 0;                                     // survivors so far (uniform)
+  for (int k0 = 0; k0 < a.S; k0 += 256) {
+    const int k = k0 + tid;
+    float4 ball = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool c = false;
+    if (k < a.S) {
+      ball = *reinterpret_cast<const float4*>(ps + (size_t)k * PS_STRIDE + PS_CULL_C);
+      float cc[3] = {ball.x, ball.y, ball.z};
+      c = nocull || cone_may_hit<float>(region, cc, ball.w);
+    }
+    unsigned long long bal = __ballot(c);
+    if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int off = n;
+    for (int w = 0; w < wave; ++w) off += s_wave_n[w];
+    if (c) {
+      int slot = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      s_ball[slot] = ball;
+      s_id[slot] = (unsigned short)k;
+    }
+    n += s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
+    __syncthreads();
+  }
+
+  // level 2: this thread's tile vs the survivors (ascending shape id)
   bool any = false;
   if (valid) {
-    Tile t = decode_tile(a, tile);
+    Tile t;
+    t.b = b; t.a0 = ty * a.P; t.b0 = tx * TILE_W;
+    t.nrows = min(a.P, a.v.rows - t.a0); t.ncols = min(TILE_W, a.v.ncols - t.b0);
     int i0, j0, i1, j1;
     pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
     pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
     Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
-    const float* ps = a.ps + (size_t)t.b * a.S * PS_STRIDE;
-    const float4* lc = s_cull + (size_t)(t.b - b_first) * a.S;
-    for (int w = 0; w < a.nwords; ++w) {
-      unsigned long long m = 0;
-      int kend = min(64, a.S - w * 64);
-      for (int kb = 0; kb < kend; ++kb) {
-        bool c = true;
-        if (!nocull) {
-          int k = w * 64 + kb;
-          float4 cr = staged ? lc[k] : *reinterpret_cast<const float4*>(ps + (size_t)k * PS_STRIDE + PS_CULL_C);
-          float cc[3] = {cr.x, cr.y, cr.z};
-          c = cone_may_hit<float>(cone, cc, cr.w);
-        }
-        m |= (unsigned long long)c << kb;
+    unsigned long long m = 0;
+    int cur = 0;                                 // mask word being assembled
+    for (int q = 0; q < n; ++q) {
+      const int k = s_id[q];
+      const int w = k >> 6;
+      while (cur < w) { mask_out[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
+      bool c = true;
+      if (!nocull) {
+        float4 ball = s_ball[q];
+        float cc[3] = {ball.x, ball.y, ball.z};
+        c = cone_may_hit<float>(cone, cc, ball.w);
       }
-      mask_out[tile * a.nwords + w] = m;
-      any |= (m != 0);
+      m |= (unsigned long long)c << (k & 63);
     }
+    while (cur < a.nwords) { mask_out[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
   }
-  // wave-aggregated append to the two lists
-  const int lane = threadIdx.x & 63;
+
+  // append to the two lists: one packed atomic per workgroup
   const unsigned long long lt = (1ull << lane) - 1ull;
-  unsigned long long bh = __ballot(valid && any), be = __ballot(valid && !any);
-  unsigned base_h = 0, base_e = 0;
-  if (lane == 0) {
-    if (bh) base_h = atomicAdd(&counts[0], (unsigned)__builtin_popcountll(bh));
-    if (be) base_e = atomicAdd(&counts[1], (unsigned)__builtin_popcountll(be));
+  const unsigned long long bh = __ballot(valid && any), be = __ballot(valid && !any);
+  if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bh) | (__builtin_popcountll(be) << 16);
+  __syncthreads();
+  int pre_h = 0, pre_e = 0, tot_h = 0, tot_e = 0;
+  for (int w = 0; w < 4; ++w) {
+    int h = s_wave_n[w] & 0xffff, e = s_wave_n[w] >> 16;
+    if (w < wave) { pre_h += h; pre_e += e; }
+    tot_h += h; tot_e += e;
   }
-  base_h = __builtin_amdgcn_readfirstlane(base_h);
-  base_e = __builtin_amdgcn_readfirstlane(base_e);
+  if (tid == 0) {
+    unsigned long long old = atomicAdd(counts, (unsigned long long)tot_h | ((unsigned long long)tot_e << 32));
+    s_base[0] = (unsigned)old;
+    s_base[1] = (unsigned)(old >> 32);
+  }
+  __syncthreads();
   if (valid) {
-    if (any) heavy_out[base_h + __builtin_popcountll(bh & lt)] = (unsigned)tile;
-    else empty_out[base_e + __builtin_popcountll(be & lt)] = (unsigned)tile;
+    if (any) heavy_out[s_base[0] + pre_h + __builtin_popcountll(bh & lt)] = (unsigned)tile;
+    else empty_out[s_base[1] + pre_e + __builtin_popcountll(be & lt)] = (unsigned)tile;
   }
 }
 
@@ -257,7 +304,31 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
   const __attribute__((address_space(4))) unsigned* heavy = (const __attribute__((address_space(4))) unsigned*)a.heavy;
   const __attribute__((address_space(4))) unsigned* empty = (const __attribute__((address_space(4))) unsigned*)a.empty;
 
+  // every wave alternates one rendered tile with its share of zero-filled
+  // tiles, so the store stream of the empty tiles runs under the arithmetic
+  // of the rendered ones
+  const unsigned my_heavy = n_heavy > (unsigned)gw ? (n_heavy - gw + a.n_waves - 1) / a.n_waves : 0;
+  const unsigned my_empty = n_empty > (unsigned)gw ? (n_empty - gw + a.n_waves - 1) / a.n_waves : 0;
+  const unsigned per = my_heavy ? (my_empty + my_heavy - 1) / my_heavy : 0;
+  unsigned eidx = gw;
+  auto zero_fill = [&](unsigned count) {
+    for (unsigned n = 0; n < count && eidx < n_empty; ++n, eidx += a.n_waves) {
+      const Tile t = decode_tile(a, empty[eidx]);
+      if (lane < t.ncols) {
+        const F3 zero = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (p < t.nrows) {
+            F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+            out[lane] = zero;
+          }
+        }
+      }
+    }
+  };
+
   for (unsigned idx = gw; idx < n_heavy; idx += a.n_waves) {
+    zero_fill(per);
     const long long tile = heavy[idx];
     const Tile t = decode_tile(a, tile);
     cuptr mk = masks + tile * a.nwords;
@@ -323,20 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
     }
   }
 
-  for (unsigned idx = gw; idx < n_empty; idx += a.n_waves) {
-    const long long tile = empty[idx];
-    const Tile t = decode_tile(a, tile);
-    if (lane < t.ncols) {
-      const F3 zero = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        if (p < t.nrows) {
-          F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
-          out[lane] = zero;
-        }
-      }
-    }
-  }
+  zero_fill(0xffffffffu);
 }
 
 // --------------------------------------------------------------- backward --
@@ -661,9 +719,11 @@ int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStr
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e);
   if (a.n_tiles > 0) {
-    hipLaunchKernelGGL(k_bin, dim3((unsigned)((a.n_tiles + 255) / 256)), dim3(256), 0, st, a,
+    long long bins = (long long)((a.tiles_x + BIN_RX - 1) / BIN_RX) * ((a.tiles_y + BIN_RY - 1) / BIN_RY) * a.B;
+    hipLaunchKernelGGL(k_bin, dim3((unsigned)bins), dim3(256), 0, st, a,
                        const_cast<unsigned long long*>(a.mask), const_cast<unsigned*>(a.heavy),
-                       const_cast<unsigned*>(a.empty), const_cast<unsigned*>(a.counts));
+                       const_cast<unsigned*>(a.empty),
+                       reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(a.counts)));
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e);
   }
