@@ -17,7 +17,7 @@ import contextlib
 import torch
 import torch.distributed as dist
 
-from . import render as _render
+from .render import _grad_hook   # the list RenderFn.backward consults (rrt.render the module is shadowed by rrt.render the function)
 
 
 def band(n_rows, rank, world_size):
@@ -41,12 +41,12 @@ def sharded(group=None):
     """Inside this context every RenderFn.backward all-reduces its flat
     gradient buffer over `group` before handing the pieces to autograd, so all
     ranks see the gradient of the WHOLE image and take identical steps."""
-    prev = _render._grad_hook[0]
-    _render._grad_hook[0] = lambda flat: all_reduce_flat(flat, group)
+    prev = _grad_hook[0]
+    _grad_hook[0] = lambda flat: all_reduce_flat(flat, group)
     try:
         yield
     finally:
-        _render._grad_hook[0] = prev
+        _grad_hook[0] = prev
 
 
 def render_band(scene, antialias_samples=4, jitter=None, group=None):
