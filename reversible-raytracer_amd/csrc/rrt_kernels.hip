@@ -56,6 +56,23 @@ struct F3 {
   float x, y, z;
 };
 
+// Diagnostic build only (-DRRT_STAMPS, tools/stamp_bwd.py): s_memtime stamps of
+// k_bwd's phases, written to a buffer nothing else reads.  Never in the shipped
+// library (MI355X_MICROARCH.md: stamps go to their own buffer; read shares, not lengths).
+#ifdef RRT_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;   // [n_tiles][8]
+#define RRT_STAMP(slot)                                                                     \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
+  } while (0)
+#else
+#define RRT_STAMP(slot) do {} while (0)
+#endif
+
 struct KArgs {
   ViewK v;
   int S, B, nwords;
@@ -66,8 +83,9 @@ struct KArgs {
   const float* ps;                // [B][S][PS_STRIDE]
   const float* hdr;               // [B][HDR_STRIDE]
   const unsigned long long* mask; // [n_tiles][nwords]
-  const unsigned* heavy;          // [n_tiles] tiles with >= 1 candidate shape (first counts[0] entries)
-  const unsigned* empty;          // [n_tiles] tiles with none              (first counts[1] entries)
+  const unsigned long long* heavy; // [n_tiles] packed entries of tiles with >= 1 candidate (first counts[0])
+  const unsigned long long* empty; // [n_tiles] packed entries of tiles with none           (first counts[1])
+  int lds_scene;                  // 1: B*S packed records fit the kernels' LDS staging area
   const unsigned* counts;         // [4]
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
@@ -78,6 +96,28 @@ struct KArgs {
 struct Tile {
   int b, a0, b0, nrows, ncols;    // scene, first row (window-relative), first column, extent
 };
+
+// Packed tile-list entry: tx[0:16) ty[16:36) b[36:52) first candidate k0[52:62) multi[62]
+// (multi = more than one candidate shape: the mask words must be consulted).
+constexpr int ENT_TX_BITS = 16, ENT_TY_BITS = 20, ENT_B_BITS = 16;
+__device__ __forceinline__ unsigned long long encode_entry(int tx, int ty, int b, int k0, bool multi) {
+  return (unsigned long long)tx | ((unsigned long long)ty << 16) | ((unsigned long long)b << 36) |
+         ((unsigned long long)k0 << 52) | ((unsigned long long)multi << 62);
+}
+__device__ __forceinline__ Tile decode_entry(const KArgs& a, unsigned long long e, int& k0, bool& multi,
+                                             long long& tile) {
+  const int tx = (int)(e & 0xffffu), ty = (int)((e >> 16) & 0xfffffu);
+  Tile t;
+  t.b = (int)((e >> 36) & 0xffffu);
+  k0 = (int)((e >> 52) & 0x3ffu);
+  multi = ((e >> 62) & 1u) != 0;
+  t.a0 = ty * a.P;
+  t.b0 = tx * TILE_W;
+  t.nrows = min(a.P, a.v.rows - t.a0);
+  t.ncols = min(TILE_W, a.v.ncols - t.b0);
+  tile = ((long long)t.b * a.tiles_y + ty) * a.tiles_x + tx;
+  return t;
+}
 
 __device__ __forceinline__ Tile decode_tile(const KArgs& a, long long tile) {
   Tile t;
@@ -119,8 +159,8 @@ __global__ void k_setup(int S, int B, const float* w2o, long long w2o_bs, const 
 // 64-bit atomic per workgroup (a same-address atomic costs ~12 ns, so per-wave
 // appends would serialise into tens of microseconds).
 constexpr int BIN_RX = 4, BIN_RY = 64;          // 4*64 tiles = 256 threads; 256 x 64P pixels
-__global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out, unsigned* heavy_out,
-                                             unsigned* empty_out, unsigned long long* counts) {
+__global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out, unsigned long long* heavy_out,
+                                             unsigned long long* empty_out, unsigned long long* counts) {
   __shared__ float4 s_ball[RRT_MAX_SHAPES];     // surviving shapes' bounding balls, list order
   __shared__ unsigned short s_id[RRT_MAX_SHAPES];
   __shared__ int s_wave_n[4];
@@ -174,6 +214,7 @@ __global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_o
 
   // level 2: this thread's tile vs the survivors (ascending shape id)
   bool any = false;
+  int k_first = 0, n_cand = 0;
   if (valid) {
     Tile t;
     t.b = b; t.a0 = ty * a.P; t.b0 = tx * TILE_W;
@@ -195,6 +236,7 @@ __global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_o
         c = cone_may_hit<float>(cone, cc, ball.w);
       }
       m |= (unsigned long long)c << (k & 63);
+      if (c) { if (!n_cand) k_first = k; ++n_cand; }
     }
     while (cur < a.nwords) { mask_out[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
   }
@@ -217,12 +259,64 @@ __global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_o
   }
   __syncthreads();
   if (valid) {
-    if (any) heavy_out[s_base[0] + pre_h + __builtin_popcountll(bh & lt)] = (unsigned)tile;
-    else empty_out[s_base[1] + pre_e + __builtin_popcountll(be & lt)] = (unsigned)tile;
+    const unsigned long long e = encode_entry(tx, ty, b, k_first, n_cand > 1);
+    if (any) heavy_out[s_base[0] + pre_h + __builtin_popcountll(bh & lt)] = e;
+    else empty_out[s_base[1] + pre_e + __builtin_popcountll(be & lt)] = e;
   }
 }
 
 // ---------------------------------------------------------------- helpers --
+constexpr int LDS_RECS = 128;          // packed shape records a workgroup stages in LDS (16 KB)
+
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ unsigned long long lane_bcast64(unsigned long long v, int src) {
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, src);
+  unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// One shape's packed record as wave-uniform scalars (SGPRs).
+struct ShapeP {
+  float A[9], o[3], colI[3], ks, kd, ka, sh;
+  int kind, powf;
+};
+
+// From the LDS copy of the scene: ONE conflict-free ds_read_b32 (lane l reads
+// word l of the 32-word record) + v_readlane broadcasts -- ~100 cycles instead
+// of a scalar-cache / L2 round trip per visit.  Falls back to scalar loads
+// when the scene does not fit the staging area.
+__device__ __forceinline__ void load_shape(const KArgs& a, const float* lds, int b, int k, int lane, ShapeP& q) {
+  if (a.lds_scene) {
+    const float v = lds[((size_t)b * a.S + k) * PS_STRIDE + (lane & 31)];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) q.A[n] = lane_bcast(v, PS_A + n);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) { q.o[n] = lane_bcast(v, PS_O + n); q.colI[n] = lane_bcast(v, PS_COLI + n); }
+    q.ks = lane_bcast(v, PS_KS); q.kd = lane_bcast(v, PS_KD); q.ka = lane_bcast(v, PS_KA); q.sh = lane_bcast(v, PS_SH);
+    q.kind = ps_load_int(lane_bcast(v, PS_KIND));
+    q.powf = ps_load_int(lane_bcast(v, PS_POWF));
+  } else {
+    cfptr r = as_const(a.ps) + ((size_t)b * a.S + k) * PS_STRIDE;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) q.A[n] = r[PS_A + n];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) { q.o[n] = r[PS_O + n]; q.colI[n] = r[PS_COLI + n]; }
+    q.ks = r[PS_KS]; q.kd = r[PS_KD]; q.ka = r[PS_KA]; q.sh = r[PS_SH];
+    q.kind = ps_load_int(r[PS_KIND]);
+    q.powf = ps_load_int(r[PS_POWF]);
+  }
+}
+
+__device__ __forceinline__ void stage_scene(const KArgs& a, float* lds) {
+  if (a.lds_scene) {
+    const int n = a.B * a.S * PS_STRIDE;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = a.ps[i];
+  }
+  __syncthreads();       // the only workgroup barrier of the render kernels (once, before the tile loop)
+}
+
 // Ray directions of this lane's P pixels for sample s.
 template <int P>
 __device__ __forceinline__ void gen_rays(const KArgs& a, const Tile& t, int lane, int s, float d[P][3]) {
@@ -238,47 +332,32 @@ __device__ __forceinline__ void gen_rays(const KArgs& a, const Tile& t, int lane
   }
 }
 
-// Winners of the composite for this lane's P rays (scene.py:38-47): candidates
-// in list order, strict '<', first wins ties.  Each candidate's parameters are
-// read once (SGPRs) and applied to all P rays.
+// One candidate against this lane's P rays (scene.py:38-47: strict '<', the
+// caller visits candidates in list order so the first wins ties).
 template <int P, bool WANT_NU>
-__device__ __forceinline__ void trace_rows(const KArgs& a, cfptr ps, cuptr mk, const float d[P][3], int best[P],
-                                           float tmin[P], float nu[P][3]) {
+__device__ __forceinline__ void trace_shape(const ShapeP& q, int k, const float d[P][3], int best[P], float tmin[P],
+                                            float nu[P][3]) {
+  if (q.kind == KIND_SPHERE) {
 #pragma unroll
-  for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
-  for (int w = 0; w < a.nwords; ++w) {
-    unsigned long long m = mk[w];
-    while (m) {
-      int kb = __builtin_ctzll(m);
-      m &= m - 1;
-      int k = w * 64 + kb;
-      cfptr q = ps + (size_t)k * PS_STRIDE;
-      float A[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
-      float o[3] = {q[PS_O], q[PS_O + 1], q[PS_O + 2]};
-      int kind = ps_load_int(q[PS_KIND]);
-      if (kind == KIND_SPHERE) {
+    for (int p = 0; p < P; ++p) {
+      float r[3];
+      xform_dir<float>(q.A, d[p], r);
+      SphereHit<float> sp;
+      bool hit = hit_sphere<float>(r, q.o, sp);
+      if (hit && sp.t < tmin[p]) {
+        tmin[p] = sp.t; best[p] = k;
+        if (WANT_NU) sphere_point<float>(sp, r, nu[p]);
+      }
+    }
+  } else {
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          float r[3];
-          xform_dir<float>(A, d[p], r);
-          SphereHit<float> sp;
-          bool hit = hit_sphere<float>(r, o, sp);
-          if (hit && sp.t < tmin[p]) {
-            tmin[p] = sp.t; best[p] = k;
-            if (WANT_NU) sphere_point<float>(sp, r, nu[p]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          float r[3], t;
-          xform_dir<float>(A, d[p], r);
-          bool hit = hit_square<float>(r, o, t);
-          if (hit && t < tmin[p]) {
-            tmin[p] = t; best[p] = k;
-            if (WANT_NU) { nu[p][0] = 0.f; nu[p][1] = 0.f; nu[p][2] = o[2] > 0.f ? 1.f : -1.f; }
-          }
-        }
+    for (int p = 0; p < P; ++p) {
+      float r[3], t;
+      xform_dir<float>(q.A, d[p], r);
+      bool hit = hit_square<float>(r, q.o, t);
+      if (hit && t < tmin[p]) {
+        tmin[p] = t; best[p] = k;
+        if (WANT_NU) { nu[p][0] = 0.f; nu[p][1] = 0.f; nu[p][2] = q.o[2] > 0.f ? 1.f : -1.f; }
       }
     }
   }
@@ -290,30 +369,42 @@ __device__ __forceinline__ int global_wave(int& lane) {
   return (int)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 }
 
+#ifndef RRT_BWD_WAVES_PER_SIMD
+#define RRT_BWD_WAVES_PER_SIMD 1
+#endif
+#ifndef RRT_FWD_WAVES_PER_SIMD
+#define RRT_FWD_WAVES_PER_SIMD 1
+#endif
+
 // ---------------------------------------------------------------- forward --
-// Persistent: every wave first walks the tiles that have candidate shapes
-// (long jobs first), then helps zero-filling the tiles that have none.
+// Persistent.  Wave gw takes entries gw, gw + n_waves, ... of the "has
+// candidates" list and of the "none" list (concurrent waves touch adjacent
+// tiles; every wave sees a fair mix of cheap and expensive tiles).  Its
+// entries are fetched 64 at a time, one per lane, and broadcast with
+// v_readlane; rendered tiles alternate with the wave's share of zero-filled
+// tiles so the store stream runs under the arithmetic.
 template <int P, int SHADER, int SPEC>
-__global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
+__global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
+  __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   const ViewK& v = a.v;
   int lane;
   const int gw = global_wave(lane);
-  cuptr masks = as_const(a.mask);
+  stage_scene(a, s_scene);
   const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
   const unsigned n_empty = ((const __attribute__((address_space(4))) unsigned*)a.counts)[1];
-  const __attribute__((address_space(4))) unsigned* heavy = (const __attribute__((address_space(4))) unsigned*)a.heavy;
-  const __attribute__((address_space(4))) unsigned* empty = (const __attribute__((address_space(4))) unsigned*)a.empty;
+  const unsigned hcount = n_heavy > (unsigned)gw ? (n_heavy - gw + a.n_waves - 1) / a.n_waves : 0;
+  const unsigned ecount = n_empty > (unsigned)gw ? (n_empty - gw + a.n_waves - 1) / a.n_waves : 0;
+  const unsigned per = hcount ? (ecount + hcount - 1) / hcount : 0;
 
-  // every wave alternates one rendered tile with its share of zero-filled
-  // tiles, so the store stream of the empty tiles runs under the arithmetic
-  // of the rendered ones
-  const unsigned my_heavy = n_heavy > (unsigned)gw ? (n_heavy - gw + a.n_waves - 1) / a.n_waves : 0;
-  const unsigned my_empty = n_empty > (unsigned)gw ? (n_empty - gw + a.n_waves - 1) / a.n_waves : 0;
-  const unsigned per = my_heavy ? (my_empty + my_heavy - 1) / my_heavy : 0;
-  unsigned eidx = gw;
+  unsigned long long ebatch = 0;       // empty-list entries, one per lane
+  unsigned ebase = 0, epos = 0;        // positions within this wave's share
   auto zero_fill = [&](unsigned count) {
-    for (unsigned n = 0; n < count && eidx < n_empty; ++n, eidx += a.n_waves) {
-      const Tile t = decode_tile(a, empty[eidx]);
+    for (unsigned n = 0; n < count && epos < ecount; ++n, ++epos) {
+      if (epos == ebase)
+        ebatch = (ebase + lane < ecount) ? a.empty[(size_t)gw + (size_t)(ebase + lane) * a.n_waves] : 0ull;
+      int k0; bool multi; long long tile;
+      const Tile t = decode_entry(a, lane_bcast64(ebatch, (int)(epos - ebase)), k0, multi, tile);
+      if (epos + 1 == ebase + 64) ebase += 64;
       if (lane < t.ncols) {
         const F3 zero = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -327,73 +418,104 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(KArgs a) {
     }
   };
 
-  for (unsigned idx = gw; idx < n_heavy; idx += a.n_waves) {
-    zero_fill(per);
-    const long long tile = heavy[idx];
-    const Tile t = decode_tile(a, tile);
-    cuptr mk = masks + tile * a.nwords;
-    cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
-    cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
-    const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
-    const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
-    float c[P][3];
+  int b_cur = -1;
+  float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
+  for (unsigned base = 0; base < hcount; base += 64) {
+    const unsigned long long hbatch =
+        (base + lane < hcount) ? a.heavy[(size_t)gw + (size_t)(base + lane) * a.n_waves] : 0ull;
+    const int nb = (int)min(64u, hcount - base);
+    for (int it = 0; it < nb; ++it) {
+      zero_fill(per);
+      int k0; bool multi; long long tile;
+      const Tile t = decode_entry(a, lane_bcast64(hbatch, it), k0, multi, tile);
+      if (t.b != b_cur) {
+        cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
+        for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
+        b_cur = t.b;
+      }
+      cuptr mk = as_const(a.mask) + tile * a.nwords;
+      float c[P][3];
 #pragma unroll
-    for (int p = 0; p < P; ++p) c[p][0] = c[p][1] = c[p][2] = 0.f;
+      for (int p = 0; p < P; ++p) c[p][0] = c[p][1] = c[p][2] = 0.f;
 #pragma unroll 1
-    for (int s = 0; s < v.A; ++s) {
-      float d[P][3], tmin[P], nu[P][3];
-      int best[P];
-      gen_rays<P>(a, t, lane, s, d);
-      trace_rows<P, SHADER == SHADER_PHONG>(a, ps, mk, d, best, tmin, nu);
-      if (SHADER == SHADER_DEPTH) {
+      for (int s = 0; s < v.A; ++s) {
+        float d[P][3], tmin[P], nu[P][3];
+        int best[P];
+        gen_rays<P>(a, t, lane, s, d);
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          if (best[p] >= 0) {
-            float x = shade_depth<float>(tmin[p], v.inv_max_depth);
-            c[p][0] += x; c[p][1] += x; c[p][2] += x;
+        for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
+        if (!multi) {
+          // one candidate: its record is read once and serves trace and shading
+          ShapeP q;
+          load_shape(a, s_scene, t.b, k0, lane, q);
+          trace_shape<P, SHADER == SHADER_PHONG>(q, k0, d, best, tmin, nu);
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (best[p] >= 0) {
+              float x[3];
+              if (SHADER == SHADER_DEPTH) x[0] = x[1] = x[2] = shade_depth<float>(tmin[p], v.inv_max_depth);
+              else shade_phong<float>(nu[p], q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SPEC, L, look, x);
+              c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
+            }
           }
-        }
-      } else {
-        // shade shape by shape: material in SGPRs, only the lanes it won are active
-        for (int w = 0; w < a.nwords; ++w) {
-          unsigned long long m = mk[w];
-          while (m) {
-            int kb = __builtin_ctzll(m);
-            m &= m - 1;
-            int k = w * 64 + kb;
-            bool mine = false;
-#pragma unroll
-            for (int p = 0; p < P; ++p) mine |= (best[p] == k);
-            if (!__ballot(mine)) continue;
-            cfptr q = ps + (size_t)k * PS_STRIDE;
-            float colI[3] = {q[PS_COLI], q[PS_COLI + 1], q[PS_COLI + 2]};
-            float ks = q[PS_KS], kd = q[PS_KD], ka = q[PS_KA], sh = q[PS_SH];
-            int powf = ps_load_int(q[PS_POWF]);
+        } else {
+          for (int w = 0; w < a.nwords; ++w) {
+            unsigned long long m = mk[w];
+            while (m) {
+              int k = w * 64 + __builtin_ctzll(m);
+              m &= m - 1;
+              ShapeP q;
+              load_shape(a, s_scene, t.b, k, lane, q);
+              trace_shape<P, SHADER == SHADER_PHONG>(q, k, d, best, tmin, nu);
+            }
+          }
+          if (SHADER == SHADER_DEPTH) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-              if (best[p] == k) {
-                float x[3];
-                shade_phong<float>(nu[p], colI, ks, kd, ka, sh, powf, SPEC, L, look, x);
-                c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
+              if (best[p] >= 0) {
+                float x = shade_depth<float>(tmin[p], v.inv_max_depth);
+                c[p][0] += x; c[p][1] += x; c[p][2] += x;
+              }
+            }
+          } else {
+            // shade shape by shape: material in SGPRs, only the lanes it won are active
+            for (int w = 0; w < a.nwords; ++w) {
+              unsigned long long m = mk[w];
+              while (m) {
+                int k = w * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                bool mine = false;
+#pragma unroll
+                for (int p = 0; p < P; ++p) mine |= (best[p] == k);
+                if (!__ballot(mine)) continue;
+                ShapeP q;
+                load_shape(a, s_scene, t.b, k, lane, q);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                  if (best[p] == k) {
+                    float x[3];
+                    shade_phong<float>(nu[p], q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SPEC, L, look, x);
+                    c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
+                  }
+                }
               }
             }
           }
         }
       }
-    }
-    // one dwordx3 per lane and row: the wave writes 768 contiguous bytes
-    if (lane < t.ncols) {
+      // one dwordx3 per lane and row: the wave writes 768 contiguous bytes
+      if (lane < t.ncols) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        if (p < t.nrows) {
-          F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
-          F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
-          out[lane] = val;
+        for (int p = 0; p < P; ++p) {
+          if (p < t.nrows) {
+            F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+            F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
+            out[lane] = val;
+          }
         }
       }
     }
   }
-
   zero_fill(0xffffffffu);
 }
 
@@ -429,11 +551,13 @@ __device__ __forceinline__ void load_grad_rows(const KArgs& a, const Tile& t, in
   }
 }
 
-// Persistent over the tiles that have candidates; tiles without never touch
-// the upstream gradient.  The next tile's gradient rows are requested before
-// the current tile is processed, so HBM latency hides behind the adjoint.
+// Persistent over the tiles that have candidates (wave gw takes entries gw,
+// gw + n_waves, ...); tiles without never touch the upstream gradient.  The
+// next tile's gradient rows are requested before the current tile is
+// processed, so HBM latency hides behind the adjoint.
 template <int P, int SHADER, int SPEC>
-__global__ __launch_bounds__(BLOCK) void k_bwd(KArgs a) {
+__global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) {
+  __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   // wave-private staging: upstream gradient (3) and winner id (1) per (row, lane)
   __shared__ float s_up[WAVES][P][3][64];
   __shared__ int s_best[WAVES][P][64];
@@ -441,109 +565,127 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(KArgs a) {
   int lane;
   const int gw = global_wave(lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  cuptr masks = as_const(a.mask);
+  stage_scene(a, s_scene);
   const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
-  const __attribute__((address_space(4))) unsigned* heavy = (const __attribute__((address_space(4))) unsigned*)a.heavy;
-  if ((unsigned)gw >= n_heavy) return;
+  const unsigned hcount = n_heavy > (unsigned)gw ? (n_heavy - gw + a.n_waves - 1) / a.n_waves : 0;
+  if (hcount == 0) return;
 
+  int b_cur = -1;
+  float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
   F3 g[P];
-  {
-    const Tile t0 = decode_tile(a, heavy[gw]);
-    load_grad_rows<P>(a, t0, lane, g);
-  }
-
-  for (unsigned idx = gw; idx < n_heavy; idx += a.n_waves) {
-    const long long tile = heavy[idx];
-    const Tile t = decode_tile(a, tile);
-    cuptr mk = masks + tile * a.nwords;
-    int ncand = 0;
-    for (int w = 0; w < a.nwords; ++w) ncand += __builtin_popcountll(mk[w]);
-    const bool col_ok = lane < t.ncols;
-
-    cfptr ps = as_const(a.ps) + (size_t)t.b * a.S * PS_STRIDE;
-    cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
-    const float L[3] = {hdr[HDR_LHAT], hdr[HDR_LHAT + 1], hdr[HDR_LHAT + 2]};
-    const float look[3] = {hdr[HDR_LOOK], hdr[HDR_LOOK + 1], hdr[HDR_LOOK + 2]};
-    float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
-
+  bool have_g = false;
+  for (unsigned base = 0; base < hcount; base += 64) {
+    const unsigned long long hbatch =
+        (base + lane < hcount) ? a.heavy[(size_t)gw + (size_t)(base + lane) * a.n_waves] : 0ull;
+    const int nb = (int)min(64u, hcount - base);
+    for (int it = 0; it < nb; ++it) {
+      int k0; bool multi; long long tile;
+      const Tile t = decode_entry(a, lane_bcast64(hbatch, it), k0, multi, tile);
+      RRT_STAMP(0);
+      if (!have_g) load_grad_rows<P>(a, t, lane, g);       // first tile of a batch: no prefetch to use
+      if (t.b != b_cur) {
+        cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
+        for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
+        b_cur = t.b;
+      }
+      const bool col_ok = lane < t.ncols;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      s_up[wave][p][0][lane] = g[p].x * v.inv_A;
-      s_up[wave][p][1][lane] = g[p].y * v.inv_A;
-      s_up[wave][p][2][lane] = g[p].z * v.inv_A;
-    }
-    // prefetch the next tile's gradient rows
-    if (idx + a.n_waves < n_heavy) {
-      const Tile tn = decode_tile(a, heavy[idx + a.n_waves]);
-      load_grad_rows<P>(a, tn, lane, g);
-    }
-    const int col = t.b0 + min(lane, t.ncols - 1);
+      for (int p = 0; p < P; ++p) {
+        s_up[wave][p][0][lane] = g[p].x * v.inv_A;
+        s_up[wave][p][1][lane] = g[p].y * v.inv_A;
+        s_up[wave][p][2][lane] = g[p].z * v.inv_A;
+      }
+      // prefetch the next tile's gradient rows
+      have_g = it + 1 < nb;
+      if (have_g) {
+        int k1; bool m1; long long tl1;
+        const Tile tn = decode_entry(a, lane_bcast64(hbatch, it + 1), k1, m1, tl1);
+        load_grad_rows<P>(a, tn, lane, g);
+      }
+      const int col = t.b0 + min(lane, t.ncols - 1);
+      cuptr mk = as_const(a.mask) + tile * a.nwords;
+      float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
+      RRT_STAMP(1);
 
 #pragma unroll 1
-    for (int s = 0; s < v.A; ++s) {
-      // phase 1: the winner of every ray (skipped when the tile has one
-      // candidate: the adjoint itself tests the hit)
-      if (ncand == 1) {
-        int k0 = 0;
-        for (int w = 0; w < a.nwords; ++w) { unsigned long long m = mk[w]; if (m) k0 = w * 64 + __builtin_ctzll(m); }
+      for (int s = 0; s < v.A; ++s) {
+        if (multi) {
+          // several candidates: settle every ray's winner first
+          float d[P][3], tmin[P];
+          int best[P];
+          gen_rays<P>(a, t, lane, s, d);
 #pragma unroll
-        for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? k0 : -1;
-      } else {
-        float d[P][3], tmin[P];
-        int best[P];
-        gen_rays<P>(a, t, lane, s, d);
-        trace_rows<P, false>(a, ps, mk, d, best, tmin, nullptr);
+          for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
+          for (int w = 0; w < a.nwords; ++w) {
+            unsigned long long m = mk[w];
+            while (m) {
+              int k = w * 64 + __builtin_ctzll(m);
+              m &= m - 1;
+              ShapeP q;
+              load_shape(a, s_scene, t.b, k, lane, q);
+              trace_shape<P, false>(q, k, d, best, tmin, nullptr);
+            }
+          }
 #pragma unroll
-        for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
-      }
-      // phase 2: wave-uniform walk over the candidate shapes
-      for (int w = 0; w < a.nwords; ++w) {
-        unsigned long long m = mk[w];
-        while (m) {
-          int kb = __builtin_ctzll(m);
+          for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
+        }
+        RRT_STAMP(2);
+        // walk the candidate shapes (one iteration for single-candidate tiles:
+        // the adjoint itself tests the hit)
+        int w = 0;
+        unsigned long long m = multi ? mk[0] : 1ull;
+        while (true) {
+          while (multi && m == 0 && ++w < a.nwords) m = mk[w];
+          if (m == 0) break;
+          const int k = multi ? w * 64 + __builtin_ctzll(m) : k0;
           m &= m - 1;
-          int k = w * 64 + kb;
-          bool mine = false;
+          if (multi) {
+            bool mine = false;
 #pragma unroll
-          for (int p = 0; p < P; ++p) mine |= (s_best[wave][p][lane] == k);
-          if (!__ballot(mine)) continue;
-          cfptr q = ps + (size_t)k * PS_STRIDE;
-          float A[9] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
-          float o[3] = {q[PS_O], q[PS_O + 1], q[PS_O + 2]};
-          float colI[3] = {q[PS_COLI], q[PS_COLI + 1], q[PS_COLI + 2]};
-          float ks = q[PS_KS], kd = q[PS_KD], ka = q[PS_KA], sh = q[PS_SH];
-          int kind = ps_load_int(q[PS_KIND]), powf = ps_load_int(q[PS_POWF]);
+            for (int p = 0; p < P; ++p) mine |= (s_best[wave][p][lane] == k);
+            if (!__ballot(mine)) continue;
+          }
+          ShapeP q;
+          load_shape(a, s_scene, t.b, k, lane, q);
           float acc[ACC_USED];
+          // the empty asm pins each accumulator to one VGPR for the whole row loop: without it
+          // hipcc keeps two copies of the block and shuffles 30 registers around the loop
+          // (160 -> 128 VGPRs, i.e. 3 -> 4 waves per SIMD)
 #pragma unroll
-          for (int n = 0; n < ACC_USED; ++n) acc[n] = 0.f;
+          for (int n = 0; n < ACC_USED; ++n) { acc[n] = 0.f; asm volatile("" : "+v"(acc[n])); }
           bool anyhit = false;
+          RRT_STAMP(3);
 #pragma unroll 1
           for (int p = 0; p < t.nrows; ++p) {
-            if (s_best[wave][p][lane] == k) {
+            const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
+            if (on) {
               int i, j;
               pixel_to_ray(v, t.a0 + p + v.row0, col, i, j);
               float sdx, sdy, d[3];
               sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
               ray_dir<float>(v, i, j, sdx, sdy, d);
               float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
-              anyhit |= adjoint_ray<float>(kind, A, o, colI, ks, kd, ka, sh, powf, SHADER, SPEC, v.inv_max_depth,
-                                           L, look, d, up, acc);
+              anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
+                                           v.inv_max_depth, L, look, d, up, acc);
             }
           }
+          RRT_STAMP(4);
           if (!__ballot(anyhit)) continue;
           // 22 wave sums -> lane n holds value n -> one 22-lane atomic
           float mine_val = 0.f;
 #pragma unroll
           for (int n = 0; n < ACC_USED; ++n) {
             float tot = wave_sum_to_lane63(acc[n]);
-            float bc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
+            float bc = lane_bcast(tot, 63);
             mine_val = (lane == n) ? bc : mine_val;
           }
           if (lane < ACC_USED)
             __hip_atomic_fetch_add(acc_scene + (size_t)k * ACC_STRIDE + lane, mine_val, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+          RRT_STAMP(5);
         }
       }
+      RRT_STAMP(6);
     }
   }
 }
@@ -649,8 +791,8 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.counts_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
   g.mask_off = g.counts_off + 16;
   g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
-  g.empty_off = align_up(g.heavy_off + (size_t)g.n_tiles * sizeof(unsigned), 16);
-  g.total = align_up(g.empty_off + (size_t)g.n_tiles * sizeof(unsigned) + 16, 16);
+  g.empty_off = align_up(g.heavy_off + (size_t)g.n_tiles * sizeof(unsigned long long), 16);
+  g.total = align_up(g.empty_off + (size_t)g.n_tiles * sizeof(unsigned long long) + 16, 16);
   return g;
 }
 
@@ -671,7 +813,11 @@ int validate(const rrt_scene* s, const rrt_view* v) {
   if (v->jitter_mode == RRT_JITTER_EXPLICIT && !v->jitter) return RRT_ERR_NULL;
   if (v->shader_id == RRT_SHADER_DEPTH && !(v->max_depth != 0.f)) return RRT_ERR_SHAPE;
   long long tiles1 = (long long)((v->transpose ? v->y_dims : v->x_dims) + TILE_W - 1) / TILE_W * v->rows * s->B;
-  if (tiles1 > 0x7fffffffLL) return RRT_ERR_SHAPE;      // tile ids are 32-bit
+  if (tiles1 > 0x7fffffffLL) return RRT_ERR_SHAPE;
+  // packed tile-list entries: 16-bit tile column, 20-bit tile row, 16-bit scene
+  if (((v->transpose ? v->y_dims : v->x_dims) + TILE_W - 1) / TILE_W > (1 << ENT_TX_BITS) ||
+      v->rows > (1 << ENT_TY_BITS) || s->B > (1 << ENT_B_BITS))
+    return RRT_ERR_SHAPE;
   return RRT_OK;
 }
 
@@ -699,8 +845,9 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.hdr = (const float*)(base + g.hdr_off);
   a.acc = (float*)(base + g.acc_off);
   a.mask = (const unsigned long long*)(base + g.mask_off);
-  a.heavy = (const unsigned*)(base + g.heavy_off);
-  a.empty = (const unsigned*)(base + g.empty_off);
+  a.heavy = (const unsigned long long*)(base + g.heavy_off);
+  a.empty = (const unsigned long long*)(base + g.empty_off);
+  a.lds_scene = ((long long)s->B * s->S <= LDS_RECS && !getenv("RRT_TUNE_NOLDS")) ? 1 : 0;
   a.counts = (const unsigned*)(base + g.counts_off);
   a.n_waves = 0;
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
@@ -721,8 +868,8 @@ int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStr
   if (a.n_tiles > 0) {
     long long bins = (long long)((a.tiles_x + BIN_RX - 1) / BIN_RX) * ((a.tiles_y + BIN_RY - 1) / BIN_RY) * a.B;
     hipLaunchKernelGGL(k_bin, dim3((unsigned)bins), dim3(256), 0, st, a,
-                       const_cast<unsigned long long*>(a.mask), const_cast<unsigned*>(a.heavy),
-                       const_cast<unsigned*>(a.empty),
+                       const_cast<unsigned long long*>(a.mask), const_cast<unsigned long long*>(a.heavy),
+                       const_cast<unsigned long long*>(a.empty),
                        reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(a.counts)));
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e);
@@ -773,6 +920,13 @@ int tuned_wgs(const char* name, int dflt) {
 }  // namespace
 
 extern "C" {
+
+#ifdef RRT_STAMPS
+int rrt_debug_set_stamps(void* dev_ptr) {
+  unsigned long long* p = (unsigned long long*)dev_ptr;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
+#endif
 
 int rrt_version(void) { return RRT_VERSION; }
 

@@ -17,7 +17,7 @@ PKG = os.path.join(REPO, "reversible-raytracer_amd")
 OUT = os.path.join(REPO, "gpurun_out", "librrt_hip_stamps.so")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-                       "-DRRT_STAMPS", "-I", os.path.join(REPO, "include"), "-I", os.path.join(PKG, "csrc"),
+                       "-DRRT_STAMPS", "-fno-slp-vectorize", "-I", os.path.join(REPO, "include"), "-I", os.path.join(PKG, "csrc"),
                        os.path.join(PKG, "csrc", "rrt_kernels.hip"), "-o", OUT])
 os.environ["RRT_LIB"] = OUT
 sys.path.insert(0, PKG)
@@ -48,8 +48,8 @@ st = stamps.cpu().numpy()[:n_tiles]
 heavy = st[:, 6] != 0
 h = st[heavy].astype(np.float64)
 print("tiles", n_tiles, "non-empty", heavy.sum())
-names = ["0->1 mask load + early-out", "1->2 decode + grad loads + LDS stage", "2->3 phase 1 (winners)",
-         "3->4 adjoint rows", "4->5 DPP reduce + atomic", "5->6 loop exit"]
+names = ["0->1 grad wait + LDS stage + prefetch issue", "1->2 phase 1 (winners; multi-candidate tiles)",
+         "2->3 load_shape", "3->4 adjoint rows", "4->5 DPP reduce + atomic", "5->6 loop exit"]
 tot = h[:, 6] - h[:, 0]
 print("total cycles/wave: median %.0f mean %.0f p90 %.0f" % (np.median(tot), tot.mean(), np.percentile(tot, 90)))
 for i, nm in enumerate(names):
@@ -59,6 +59,5 @@ for i, nm in enumerate(names):
     if len(d):
         print("  %-40s median %8.0f mean %8.0f  share %5.1f%%  (n=%d)" % (nm, np.median(d), d.mean(),
                                                                          100 * d.sum() / tot.sum(), len(d)))
-span = st[heavy][:, 6].max() - st[heavy][:, 0].min()
-print("kernel span (first start -> last end of non-empty waves): %d cycles; sum of wave lifetimes / span = %.1f waves"
-      % (span, tot.sum() / span))
+single = h[:, 2] - h[:, 1] < 200
+print("single-candidate tiles: %d; their adjoint rows median %.0f cycles" % (single.sum(), np.median((h[:, 4] - h[:, 3])[single])))
