@@ -41,8 +41,10 @@ namespace {
 using namespace rrt;
 
 constexpr int TILE_W = 64;      // one lane per pixel column: a wave row is 768 contiguous bytes
-constexpr int WAVES = 4;        // waves (= tiles) per workgroup
-constexpr int BLOCK = WAVES * 64;
+constexpr int WAVES = 16;       // waves per k_bwd workgroup: ONE 1024-thread workgroup fills a CU at the
+constexpr int BLOCK = WAVES * 64;   // kernel's 4 waves/SIMD, so its LDS work queue balances the whole CU
+constexpr int WAVES_F = 4;      // waves per k_fwd workgroup (statically dealt tiles: no coupling wanted)
+constexpr int BLOCK_F = WAVES_F * 64;
 constexpr int MAX_WORDS = RRT_MAX_SHAPES / 64;
 
 // Wave-uniform read-only data goes through the constant address space so the
@@ -69,8 +71,15 @@ __device__ unsigned long long* g_stamps = nullptr;   // [n_tiles][8]
     __builtin_amdgcn_sched_barrier(0);                                                      \
     if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
   } while (0)
+#define RRT_STAMP_RT(slot)                                                                  \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+    if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
+  } while (0)
 #else
 #define RRT_STAMP(slot) do {} while (0)
+#define RRT_STAMP_RT(slot) do {} while (0)
 #endif
 
 struct KArgs {
@@ -363,10 +372,48 @@ __device__ __forceinline__ void trace_shape(const ShapeP& q, int k, const float 
   }
 }
 
+template <int NW>
 __device__ __forceinline__ int global_wave(int& lane) {
   lane = threadIdx.x & 63;
   // provably wave-uniform => SGPR addressing downstream
-  return (int)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return (int)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+}
+
+// ---- per-workgroup work queue ------------------------------------------------
+// Workgroup wg owns entries wg, wg + n_wgs, ... of a tile list (a fair, spatially
+// interleaved share).  They are copied into LDS once and handed to the
+// workgroup's 16 waves through an LDS cursor (ds_add_rtn: ~100 cycles, no global
+// atomics): a tile costs 1x..3x depending on its candidates and coverage, and a
+// static deal per WAVE left most SIMDs idle behind the unluckiest wave
+// (profiles/: 2.6 of 4 resident waves busy on average).
+constexpr int Q_CAP = 1024;            // entries staged per batch
+struct WgQueue {
+  unsigned long long ent[Q_CAP];
+  unsigned cursor;
+};
+
+// All 1024 threads: stage batch `batch` of this workgroup's share; returns its size.
+__device__ __forceinline__ unsigned queue_fill(WgQueue& q, const unsigned long long* list, unsigned n, unsigned batch) {
+  const unsigned share = n > blockIdx.x ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const unsigned lo = batch * Q_CAP;
+  const unsigned cnt = share > lo ? min((unsigned)Q_CAP, share - lo) : 0;
+  __syncthreads();                                   // previous batch fully consumed
+  for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x)
+    q.ent[i] = list[(size_t)blockIdx.x + (size_t)(lo + i) * gridDim.x];
+  if (threadIdx.x == 0) q.cursor = 0;
+  __syncthreads();
+  return cnt;
+}
+
+// One wave: next entry of the batch, or false when it is exhausted.
+__device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, unsigned long long& e) {
+  unsigned i = 0;
+  if (lane == 0) i = atomicAdd(&q.cursor, 1u);
+  i = __builtin_amdgcn_readfirstlane(i);
+  if (i >= cnt) return false;
+  e = q.ent[i];
+  e = lane_bcast64(e, 0);
+  return true;
 }
 
 #ifndef RRT_BWD_WAVES_PER_SIMD
@@ -384,11 +431,11 @@ __device__ __forceinline__ int global_wave(int& lane) {
 // v_readlane; rendered tiles alternate with the wave's share of zero-filled
 // tiles so the store stream runs under the arithmetic.
 template <int P, int SHADER, int SPEC>
-__global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
+__global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   const ViewK& v = a.v;
   int lane;
-  const int gw = global_wave(lane);
+  const int gw = global_wave<WAVES_F>(lane);
   stage_scene(a, s_scene);
   const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
   const unsigned n_empty = ((const __attribute__((address_space(4))) unsigned*)a.counts)[1];
@@ -551,60 +598,78 @@ __device__ __forceinline__ void load_grad_rows(const KArgs& a, const Tile& t, in
   }
 }
 
-// Persistent over the tiles that have candidates (wave gw takes entries gw,
-// gw + n_waves, ...); tiles without never touch the upstream gradient.  The
-// next tile's gradient rows are requested before the current tile is
-// processed, so HBM latency hides behind the adjoint.
+// Persistent over the tiles that have candidates (tiles without never touch
+// the upstream gradient), pulled from the workgroup's LDS queue.  The next
+// tile's gradient rows are requested before the current tile is processed, so
+// HBM latency hides behind the adjoint.
 template <int P, int SHADER, int SPEC>
 __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
+  __shared__ WgQueue s_q;
   // wave-private staging: upstream gradient (3) and winner id (1) per (row, lane)
   __shared__ float s_up[WAVES][P][3][64];
   __shared__ int s_best[WAVES][P][64];
   const ViewK& v = a.v;
   int lane;
-  const int gw = global_wave(lane);
+  global_wave<WAVES>(lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   stage_scene(a, s_scene);
   const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
-  const unsigned hcount = n_heavy > (unsigned)gw ? (n_heavy - gw + a.n_waves - 1) / a.n_waves : 0;
-  if (hcount == 0) return;
+  const unsigned wg_share = n_heavy > blockIdx.x ? (n_heavy - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 
   int b_cur = -1;
   float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
-  F3 g[P];
-  bool have_g = false;
-  for (unsigned base = 0; base < hcount; base += 64) {
-    const unsigned long long hbatch =
-        (base + lane < hcount) ? a.heavy[(size_t)gw + (size_t)(base + lane) * a.n_waves] : 0ull;
-    const int nb = (int)min(64u, hcount - base);
-    for (int it = 0; it < nb; ++it) {
+  // the last accumulator flush of a tile is held back into the next iteration: issued at
+  // the end of its tile it would sit in front of the next tile's wait for its (older)
+  // gradient loads -- the vector-memory counter retires in order
+  bool held = false;
+  int held_k = 0, held_b = 0;
+  float held_val = 0.f;
+
+  for (unsigned batch = 0; batch * Q_CAP < wg_share; ++batch) {
+    const unsigned cnt = queue_fill(s_q, a.heavy, n_heavy, batch);
+    unsigned long long e_cur = 0, e_nxt = 0;
+    bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
+    F3 g[P];
+    if (has_cur) {
       int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, lane_bcast64(hbatch, it), k0, multi, tile);
+      const Tile t = decode_entry(a, e_cur, k0, multi, tile);
+      load_grad_rows<P>(a, t, lane, g);
+    }
+    while (has_cur) {
+      int k0; bool multi; long long tile;
+      const Tile t = decode_entry(a, e_cur, k0, multi, tile);
       RRT_STAMP(0);
-      if (!have_g) load_grad_rows<P>(a, t, lane, g);       // first tile of a batch: no prefetch to use
+      RRT_STAMP_RT(7);
       if (t.b != b_cur) {
         cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
         for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
         b_cur = t.b;
       }
       const bool col_ok = lane < t.ncols;
+      // (1) this tile's gradient rows, requested one tile ago
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         s_up[wave][p][0][lane] = g[p].x * v.inv_A;
         s_up[wave][p][1][lane] = g[p].y * v.inv_A;
         s_up[wave][p][2][lane] = g[p].z * v.inv_A;
       }
-      // prefetch the next tile's gradient rows
-      have_g = it + 1 < nb;
-      if (have_g) {
+      // (2) the accumulator atomic held back from the previous tile
+      if (held) {
+        if (lane < ACC_USED)
+          __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        held = false;
+      }
+      // (3) pull the next tile and request its gradient rows
+      const bool has_nxt = queue_pop(s_q, cnt, lane, e_nxt);
+      if (has_nxt) {
         int k1; bool m1; long long tl1;
-        const Tile tn = decode_entry(a, lane_bcast64(hbatch, it + 1), k1, m1, tl1);
+        const Tile tn = decode_entry(a, e_nxt, k1, m1, tl1);
         load_grad_rows<P>(a, tn, lane, g);
       }
       const int col = t.b0 + min(lane, t.ncols - 1);
       cuptr mk = as_const(a.mask) + tile * a.nwords;
-      float* acc_scene = a.acc + (size_t)t.b * a.S * ACC_STRIDE;
       RRT_STAMP(1);
 
 #pragma unroll 1
@@ -679,15 +744,22 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
             float bc = lane_bcast(tot, 63);
             mine_val = (lane == n) ? bc : mine_val;
           }
-          if (lane < ACC_USED)
-            __hip_atomic_fetch_add(acc_scene + (size_t)k * ACC_STRIDE + lane, mine_val, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+          if (held && lane < ACC_USED)
+            __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          held = true; held_k = k; held_b = t.b; held_val = mine_val;
           RRT_STAMP(5);
         }
       }
       RRT_STAMP(6);
+      RRT_STAMP_RT(2);     // overwrites the phase-1 stamp: real time at the end of the tile
+      e_cur = e_nxt;
+      has_cur = has_nxt;
     }
   }
+  if (held && lane < ACC_USED)
+    __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // --------------------------------------------------------------- finalize --
@@ -894,14 +966,15 @@ int device_cus() {
 unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
   long long want = (long long)device_cus() * wgs_per_cu;
   long long need = (n_tiles + WAVES - 1) / WAVES;
+  if (need < 1) need = 1;
   return (unsigned)(want < need ? want : need);
 }
 
 template <int P>
 void launch_fwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
-  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK_F), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK_F), 0, st, a);
+  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK_F), 0, st, a);
 }
 
 template <int P>
@@ -975,8 +1048,10 @@ int rrt_render_fwd(const rrt_scene* s, const rrt_view* v, float* image_out, void
     if (rc != RRT_OK) return rc;
   }
   if (g.n_tiles == 0) return RRT_OK;
-  unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_FWD_WGS", 8));
-  a.n_waves = (int)blocks * WAVES;
+  long long want = (long long)device_cus() * tuned_wgs("RRT_TUNE_FWD_WGS", 8);
+  long long need = (g.n_tiles + WAVES_F - 1) / WAVES_F;
+  unsigned blocks = (unsigned)(want < need ? want : need);
+  a.n_waves = (int)blocks * WAVES_F;
   if (g.P == 4) launch_fwd<4>(a, blocks, a.v.shader, a.v.specular, st);
   else if (g.P == 2) launch_fwd<2>(a, blocks, a.v.shader, a.v.specular, st);
   else launch_fwd<1>(a, blocks, a.v.shader, a.v.specular, st);
@@ -1001,7 +1076,7 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
   }
   hipError_t e;
   if (g.n_tiles > 0 && s->S > 0) {
-    unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 4));
+    unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 1));
     a.n_waves = (int)blocks * WAVES;
     if (g.P == 4) launch_bwd<4>(a, blocks, a.v.shader, a.v.specular, st);
     else if (g.P == 2) launch_bwd<2>(a, blocks, a.v.shader, a.v.specular, st);

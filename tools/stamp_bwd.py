@@ -59,5 +59,12 @@ for i, nm in enumerate(names):
     if len(d):
         print("  %-40s median %8.0f mean %8.0f  share %5.1f%%  (n=%d)" % (nm, np.median(d), d.mean(),
                                                                          100 * d.sum() / tot.sum(), len(d)))
+rt = (h[:, 2] - h[:, 7])            # s_memrealtime ticks (100 MHz) over the tile
+ok = rt > 0
+print("in-kernel clock: %.2f GHz (median over tiles of d(s_memtime)/d(s_memrealtime) x 100 MHz)" %
+      (np.median((h[:, 6] - h[:, 0])[ok] / rt[ok]) * 0.1))
+t_first, t_last = h[:, 7].min(), h[:, 2].max()
+print("kernel span by s_memrealtime: %.1f us; sum of tile wave-times / span = %.2f waves per SIMD" %
+      ((t_last - t_first) / 100.0, (rt[ok].sum() / (t_last - t_first)) / 1024.0))
 single = h[:, 2] - h[:, 1] < 200
 print("single-candidate tiles: %d; their adjoint rows median %.0f cycles" % (single.sum(), np.median((h[:, 4] - h[:, 3])[single])))
