@@ -89,6 +89,7 @@ class Job(object):
         self.v_fwd = view(0)
         self.v_fwd_reuse = view(N.FLAG_REUSE_SETUP)
         self.v_bwd = view(N.FLAG_REUSE_SETUP)      # the packed scene of the step's forward is still valid
+        self.v_bwd_only = view(N.FLAG_REUSE_SETUP | N.FLAG_SKIP_FINALIZE)   # k_bwd alone (kernel timing)
         nbytes = self.L.rrt_workspace_bytes(ctypes.byref(sc), ctypes.byref(self.v_fwd))
         assert nbytes > 0
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -104,10 +105,11 @@ class Job(object):
                                    self.ws.numel(), self.stream)
         self.N.check(rc, "rrt_render_fwd")
 
-    def bwd(self):
+    def bwd(self, kernel_only=False):
         S = self.S
         base = self.flat.data_ptr()
-        rc = self.L.rrt_render_bwd(ctypes.byref(self.sc), ctypes.byref(self.v_bwd), self._p(self.grad),
+        v = self.v_bwd_only if kernel_only else self.v_bwd
+        rc = self.L.rrt_render_bwd(ctypes.byref(self.sc), ctypes.byref(v), self._p(self.grad),
                                    ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * S * 12),
                                    ctypes.c_void_p(base + 4 * S * 19), self._p(self.ws), self.ws.numel(), self.stream)
         self.N.check(rc, "rrt_render_bwd")
@@ -196,22 +198,34 @@ def main():
         torch.cuda.synchronize()
         for i in range(n):
             ev[i][0].record()
-            job.fwd(reuse=True)          # k_fwd alone (packed scene reused)
+            job.fwd(reuse=True)              # k_fwd alone (packed scene + tile lists reused)
             ev[i][1].record()
-            job.bwd()                    # memset + k_bwd + k_finalize
+            job.bwd(kernel_only=True)        # k_bwd alone (RRT_FLAG_SKIP_FINALIZE)
             ev[i][2].record()
+        job.fwd()                            # re-pack: rewinds the accumulators the kernel-only calls left dirty
         torch.cuda.synchronize()
         t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
         t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
         px = rows * args.size
-        kernels = {"k_fwd_us": t_f * 1e6, "bwd_group_us": t_b * 1e6,
+        kernels = {"k_fwd_us": t_f * 1e6, "k_bwd_us": t_b * 1e6,
                    "k_fwd_GBs": px * BYTES_PER_PIXEL_FWD / t_f / 1e9,
-                   "bwd_group_GBs": px * BYTES_PER_PIXEL_BWD / t_b / 1e9,
+                   "k_bwd_GBs": px * BYTES_PER_PIXEL_BWD / t_b / 1e9,
                    "fwd_plus_bwd_GBs": px * (BYTES_PER_PIXEL_FWD + BYTES_PER_PIXEL_BWD) / (t_f + t_b) / 1e9}
         dom_fwd = t_f >= t_b
-        ach = kernels["k_fwd_GBs"] if dom_fwd else kernels["bwd_group_GBs"]
+        ach = kernels["k_fwd_GBs"] if dom_fwd else kernels["k_bwd_GBs"]
+        # HBM bytes per launch from the committed PMC passes (same workload only)
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            tj = json.load(open(tpath))
+            w = tj["workload"]
+            if (w["size"], w["spheres"], w["aa"]) == (args.size, args.spheres, args.aa):
+                k = tj["k_fwd"] if dom_fwd else tj["k_bwd"]
+                traffic = (k["write_bytes"] + k["fetch_bytes_raw"]) if dom_fwd else (k["fetch_bytes_x2"] + k["write_bytes"])
         roofline = {"bound": "hbm", "kernel": "k_fwd" if dom_fwd else "k_bwd", "achieved": ach,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "note": None if dom_fwd else "k_bwd skips the gradient of tiles no shape can hit and is bound by "
+                                                 "FP32 VALU issue at this coverage, not by HBM (DESIGN.md section 6)"}
 
     if rank == 0:
         cpu = None

@@ -71,6 +71,11 @@ typedef enum rrt_status {
                                     (backward right after its forward; repeated
                                     forwards of an unchanged scene) */
 
+#define RRT_FLAG_SKIP_FINALIZE 4u /* rrt_render_bwd, measurement only: run the adjoint kernel but not the
+                                    final chain to w2o/material/light (g_* are left untouched and the
+                                    accumulators un-rewound: a normal rrt_render_bwd WITHOUT
+                                    RRT_FLAG_REUSE_SETUP must follow before gradients are used again) */
+
 /* Scene parameters: everything Scene.build() reads from its shapes and
  * lights[0] (scene.py:12-16).  B >= 1 scenes are rendered by one call; an
  * array with batch stride 0 is shared by all B scenes (its gradient is then

@@ -1084,6 +1084,7 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e);
   }
+  if (v->flags & RRT_FLAG_SKIP_FINALIZE) return RRT_OK;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, s->S, s->B, a.acc, a.hdr, s->material,
                      (long long)s->material_bstride, s->light, (long long)s->w2o_bstride, g_w2o, g_material,
                      g_light);

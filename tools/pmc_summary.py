@@ -6,15 +6,22 @@ import csv
 import os
 import sys
 
+def find(d, name):
+    for root, _, files in os.walk(d):
+        if name in files:
+            return os.path.join(root, name)
+    return os.path.join(d, name)
+
+
 for d in sys.argv[1:]:
-    st = os.path.join(d, "bench_kernel_stats.csv")
+    st = find(d, "bench_kernel_stats.csv")
     if os.path.exists(st):
         print("==", st)
         for r in csv.DictReader(open(st)):
             name = r["Name"].replace("(anonymous namespace)::", "")[:60]
             print("  %-62s calls %4s avg %10.1f ns  min %8s max %8s  %5s%%" % (
                 name, r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"][:5]))
-    cc = os.path.join(d, "bench_counter_collection.csv")
+    cc = find(d, "bench_counter_collection.csv")
     if os.path.exists(cc):
         print("==", cc)
         rows = list(csv.DictReader(open(cc)))
