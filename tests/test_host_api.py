@@ -195,3 +195,18 @@ def test_synthetic_scenes_are_reproducible():
     c = -w2o[:, :, 3] * rho[:, None]
     assert (rho >= .15).all() and (rho <= .45).all() and (c[:, 2] >= 4).all() and (c[:, 2] <= 12).all()
     assert (np.abs(c[:, 0] / c[:, 2]) <= .4 + 1e-6).all()
+
+
+def test_dataset_writers_use_the_reference_layout(tmp_path):
+    from rrt import dataset
+    rs = np.random.RandomState(0)
+    renders = [rs.rand(8, 8, 3).astype("float32") for _ in range(3)]
+    d = dataset.save_depth_dataset(str(tmp_path / "dataset"), renders)          # generate_data.py:44-52
+    assert d.shape == (3, 8, 8) and d.dtype == np.uint8
+    assert np.array_equal(d[1], (renders[1][:, :, 0] * 255).astype(np.uint8))
+    pairs = [(rs.rand(8, 8, 3), rs.rand(8, 8, 3)) for _ in range(2)]
+    o = dataset.save_orbit_dataset(str(tmp_path / "orbit"), pairs, [(1, 2, 32.)] * 2, str(tmp_path / "orbit_target"))
+    assert o.shape == (2, 2, 8, 8, 3)                                            # planet_orbit.py:56
+    back = dataset.load_dataset(str(tmp_path / "orbit.npz"))                     # test_optimization.py:56-57
+    assert back.dtype == np.float32 and np.allclose(back, o / 255.0)
+    assert np.load(str(tmp_path / "orbit_target.npz"))["arr_0"].shape == (2, 3)
