@@ -30,7 +30,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--spheres", type=int, default=32)
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--aa", type=int, default=1)
+ap.add_argument("--onebig", action="store_true", help="one sphere covering 87 %% of the image: uniform single-candidate tiles")
 args = ap.parse_args()
+if args.onebig:
+    from rrt import synthetic
+
+    def one_big(S, seed=0):
+        w2o = synthetic._w2o_translate_scale((0.0, 0.0, 4.0), 1.9)[None].astype(np.float32)
+        return (w2o, np.array([[0.2, 0.9, 0.4, 0.3, 0.7, 0.5, 50.0]], np.float32),
+                np.array([-1.0, -1.0, 2.0, 0.961, 1.0, 0.87], np.float32), np.zeros(1, np.uint8))
+    synthetic.random_spheres = one_big
+    args.spheres = 1
 dev = torch.device("cuda:0")
 job = bench.Job(dev, args.size, args.spheres, args.aa, 0, args.size, True)
 job.fwd()
