@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--spheres", type=int, default=32)
     ap.add_argument("--aa", type=int, default=1)
     ap.add_argument("--no-cull", action="store_true")
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"],
+                    help="c4 (default, the headline): --spheres random spheres at --size^2; c2: 1 sphere Phong 512^2; "
+                         "c3: match_mirror scene (2 spheres + square) 1024^2, A=4; c5: 256 orbit scenes of 64^2, A=4")
     ap.add_argument("--cpu-rows", type=int, default=256, help="rows of the CPU-baseline band (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -56,21 +59,39 @@ def parse():
 class Job(object):
     """Direct C-ABI driver (no autograd in the timed region)."""
 
-    def __init__(self, dev, size, spheres, aa, row0, rows, cull):
+    def __init__(self, dev, size, spheres, aa, row0, rows, cull, workload="c4"):
         from rrt import _native as N
         from rrt import synthetic
         self.N = N
         self.L = N.lib()
-        w2o, mat, light, kinds = synthetic.random_spheres(spheres, seed=0)
+        B, specular, transpose, jitter_mode, seed = 1, 1, 1, N.JITTER_CENTER, 0
+        cam = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0], dtype=np.float32)
+        if workload == "c2":
+            w2o, mat, light, kinds = synthetic.one_sphere()
+        elif workload == "c3":
+            w2o, mat, light, kinds = synthetic.match_mirror(True)
+            jitter_mode, seed = N.JITTER_HASH, 1
+        elif workload == "c5":
+            rs = np.random.RandomState(0)
+            B = 256
+            _, mat, light, kinds = synthetic.orbit_scene()
+            ang = rs.uniform(0, 2 * np.pi, B)
+            w2o = np.stack([synthetic.orbit_scene((9 * np.cos(t), 9 * np.sin(t), 32.0))[0] for t in ang])
+            cam = np.stack([synthetic.orbit_camera(2.5 if b % 2 == 0 else -2.5) for b in range(B)])
+            specular, transpose, jitter_mode, seed = 0, 0, N.JITTER_HASH, 1
+        else:
+            w2o, mat, light, kinds = synthetic.random_spheres(spheres, seed=0)
+        spheres = w2o.shape[-3]
+        self.B = B
         self.w2o = torch.tensor(w2o, device=dev)
         self.mat = torch.tensor(mat, device=dev)
         self.light = torch.tensor(light, device=dev)
         self.kinds = torch.tensor(kinds, device=dev)
-        self.cam = torch.tensor([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0], dtype=torch.float32, device=dev)
+        self.cam = torch.tensor(cam, device=dev)
         self.S, self.size, self.rows, self.row0 = spheres, size, rows, row0
         sc = N.RrtScene()
-        sc.S, sc.B = spheres, 1
-        sc.w2o, sc.w2o_bstride = self.w2o.data_ptr(), 0
+        sc.S, sc.B = spheres, B
+        sc.w2o, sc.w2o_bstride = self.w2o.data_ptr(), (spheres * 12 if B > 1 else 0)
         sc.material, sc.material_bstride = self.mat.data_ptr(), 0
         sc.light, sc.kind = self.light.data_ptr(), self.kinds.data_ptr()
         self.sc = sc
@@ -80,11 +101,11 @@ class Job(object):
             vw.x_dims = vw.y_dims = size
             vw.antialias_samples = aa
             vw.row0, vw.rows = row0, rows
-            vw.shader_id, vw.specular, vw.transpose = N.SHADER_PHONG, 1, 1
-            vw.jitter_mode, vw.seed = N.JITTER_CENTER, 0
+            vw.shader_id, vw.specular, vw.transpose = N.SHADER_PHONG, specular, transpose
+            vw.jitter_mode, vw.seed = jitter_mode, seed
             vw.flags = flags | (0 if cull else N.FLAG_NO_CULL)
             vw.max_depth = 1.0
-            vw.cam, vw.cam_bstride, vw.jitter = self.cam.data_ptr(), 0, None
+            vw.cam, vw.cam_bstride, vw.jitter = self.cam.data_ptr(), (16 if B > 1 else 0), None
             return vw
         self.v_fwd = view(0)
         self.v_fwd_reuse = view(N.FLAG_REUSE_SETUP)
@@ -93,9 +114,9 @@ class Job(object):
         nbytes = self.L.rrt_workspace_bytes(ctypes.byref(sc), ctypes.byref(self.v_fwd))
         assert nbytes > 0
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self.image = torch.empty((rows, size, 3), dtype=torch.float32, device=dev)
+        self.image = torch.empty((B, rows, size, 3), dtype=torch.float32, device=dev)
         self.grad = torch.empty_like(self.image)
-        self.flat = torch.zeros(spheres * 12 + spheres * 7 + 6, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(B * spheres * 12 + spheres * 7 + 6, dtype=torch.float32, device=dev)
         self.stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         self._p = lambda t: ctypes.c_void_p(t.data_ptr())
 
@@ -106,12 +127,13 @@ class Job(object):
         self.N.check(rc, "rrt_render_fwd")
 
     def bwd(self, kernel_only=False):
-        S = self.S
+        S, B = self.S, self.B
         base = self.flat.data_ptr()
         v = self.v_bwd_only if kernel_only else self.v_bwd
         rc = self.L.rrt_render_bwd(ctypes.byref(self.sc), ctypes.byref(v), self._p(self.grad),
-                                   ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * S * 12),
-                                   ctypes.c_void_p(base + 4 * S * 19), self._p(self.ws), self.ws.numel(), self.stream)
+                                   ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * B * S * 12),
+                                   ctypes.c_void_p(base + 4 * (B * S * 12 + S * 7)), self._p(self.ws), self.ws.numel(),
+                                   self.stream)
         self.N.check(rc, "rrt_render_bwd")
 
 
@@ -152,12 +174,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from rrt.dist import band
+    if args.workload == "c2":
+        args.size, args.aa = 512, 1
+    elif args.workload == "c3":
+        args.size, args.aa = 1024, 4
+    elif args.workload == "c5":
+        args.size, args.aa = 64, 4
     row0, rows = band(args.size, rank, world)
-    job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull)
+    job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull, args.workload)
+    args.spheres = job.S
 
     # upstream gradient of the match_mirror loss, computed once: g = 2 (image - fliplr(image0))
     job.fwd()
-    job.grad.copy_(2.0 * (job.image - torch.flip(job.image, dims=[1])))
+    job.grad.copy_(2.0 * (job.image - torch.flip(job.image, dims=[2])))
     torch.cuda.synchronize()
 
     def step():
@@ -185,7 +214,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
-    rays = args.size * args.size * args.aa
+    rays = job.B * args.size * args.size * args.aa
     value = rays / (elapsed / args.steps) / 1e6
 
     # per-kernel durations, HIP events on the launch stream (torch's current stream)
@@ -206,7 +235,7 @@ def main():
         torch.cuda.synchronize()
         t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
         t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
-        px = rows * args.size
+        px = job.B * rows * args.size
         kernels = {"k_fwd_us": t_f * 1e6, "k_bwd_us": t_b * 1e6,
                    "k_fwd_GBs": px * BYTES_PER_PIXEL_FWD / t_f / 1e9,
                    "k_bwd_GBs": px * BYTES_PER_PIXEL_BWD / t_b / 1e9,
@@ -229,16 +258,21 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and args.cpu_rows > 0:
+        if world == 1 and args.cpu_rows > 0 and args.workload == "c4":
             cpu = cpu_baseline(args.size, args.spheres, args.aa, args.cpu_rows)
         out = {
             "metric": "Mrays/s fwd+bwd at %dx%d/%d spheres" % (args.size, args.size, args.spheres),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d random spheres (seed 0), %dx%d, antialias_samples=%d, Phong+specular, "
-                                   "root camera, dense upstream grad; row bands over %d GPU(s)"
-                                   % (args.spheres, args.size, args.size, args.aa, world),
+            "config": {"workload": {"c4": "%d random spheres (seed 0), %dx%d, antialias_samples=%d, Phong+specular, "
+                                          "root camera, dense upstream grad; row bands over %d GPU(s)"
+                                          % (args.spheres, args.size, args.size, args.aa, world),
+                                    "c2": "config 2: 1 sphere Phong, 512x512, antialias_samples=1",
+                                    "c3": "config 3: match_mirror.py scene (2 spheres + square), 1024x1024, "
+                                          "antialias_samples=4, hash jitter",
+                                    "c5": "config 5: 256 orbit scenes (2 spheres, stereo cameras, no specular), 64x64, "
+                                          "antialias_samples=4, one batched launch"}[args.workload],
                        "cull": not args.no_cull, "parallelism": "rowband%d" % world},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
