@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"],
                     help="c4 (default, the headline): --spheres random spheres at --size^2; c2: 1 sphere Phong 512^2; "
                          "c3: match_mirror scene (2 spheres + square) 1024^2, A=4; c5: 256 orbit scenes of 64^2, A=4")
-    ap.add_argument("--cpu-rows", type=int, default=256, help="rows of the CPU-baseline band (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline band (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
