@@ -1,35 +1,41 @@
 // rrt_kernels.hip -- gfx950 (MI355X, CDNA4) render kernels + the C ABI of rrt.h.
 //
-// Kernels of one forward/backward pair (DESIGN.md has the full story):
+// Kernels of one forward/backward pair (DESIGN.md section 5 has the full story
+// and the measurements behind every choice):
 //
 //   k_setup     one thread per (scene, shape): fold the camera into the shape
 //               transform, precompute per-shape constants and a camera-local
 //               bounding ball (one 128-B record per shape), zero the shape's
-//               gradient-accumulator row.
-//   k_bin       one thread per wave tile (64 x P pixels): cone-vs-ball test of
-//               every shape -> a candidate bit mask per tile (8 B per 64 shapes).
-//   k_fwd<P>    one WAVE per tile, one lane per pixel column, P rows per lane.
-//               The tile's mask arrives by scalar load; candidate shapes are
-//               visited in list order with their parameters in SGPRs (s_load
-//               through the constant address space: no VGPRs, no LDS), rays are
-//               generated in registers, winners are shaded shape by shape, and
-//               each lane stores its RGB triple with one global_store_dwordx3
-//               (a wave row is 768 contiguous bytes).  Tiles without candidates
-//               only store zeros.
-//   k_bwd<P>    same tiling; tiles without candidates exit before touching the
-//               upstream gradient.  All P gradient rows are requested up front
-//               (one dwordx3 per lane and row).  For every candidate shape that
+//               gradient-accumulator row and the tile-list counters.
+//   k_bin       workgroup = a 4 x 64 block of wave tiles (a tile is 64 x P
+//               pixels): two-level cone-vs-ball cull -> a candidate bit mask per
+//               tile; packed tile entries are appended to a "has candidates"
+//               and a "none" list with one packed atomic per workgroup.
+//   k_fwd<P>    persistent; one WAVE per tile, one lane per pixel column, P rows
+//               per lane.  List entries arrive 64 at a time (one per lane,
+//               v_readlane); the packed scene is staged in LDS once and a
+//               shape's record reaches SGPRs by one ds_read_b32 + v_readlane
+//               (scalar loads through the constant address space when the scene
+//               is too big); rays are generated in registers; winners are
+//               shaded shape by shape; each lane stores its RGB triple with one
+//               global_store_dwordx3 (a wave row is 768 contiguous bytes).
+//               Tiles without candidates are only zero-filled.
+//   k_bwd<P>    persistent, one 1024-thread workgroup per CU with an LDS work
+//               queue; tiles without candidates never touch the upstream
+//               gradient; the next tile's gradient rows are requested before
+//               the current tile's arithmetic.  For every candidate shape that
 //               won somewhere in the wave, the lanes it won run the analytic
 //               adjoint with the shape's parameters in SGPRs and add into 22
 //               per-lane accumulators; these are summed across the wave with
-//               DPP (quad_perm / row_shr / row_bcast) and leave as ONE 22-lane
-//               global_atomic_add_f32 per (wave, sample, shape).
+//               DPP (quad_perm / row_shr / row_bcast), added to workgroup-level
+//               LDS accumulators, and each workgroup adds a touched shape row
+//               to HBM once (global_atomic_add_f32).
 //   k_finalize  chain the accumulator rows back to w2o / material / light and
 //               re-zero them.
 //
-// Waves never talk to each other: no __syncthreads, LDS only as wave-private
-// staging in k_bwd.  No MFMA: the path is per-ray quadratic solves, not a
-// contraction.
+// No MFMA: the path is per-ray quadratic solves, not a contraction.
+// Environment variables RRT_TUNE_* are tuning knobs for experiments (tile rows,
+// persistent grid sizes, LDS staging on/off); defaults are what was measured best.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
