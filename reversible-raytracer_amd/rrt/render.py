@@ -183,8 +183,16 @@ class RenderFn(torch.autograd.Function):
 _grad_hook = [None]
 
 
+_default_cams = {}
+
+
 def default_cam(device):
-    return torch.tensor(_IDENT_CAM, dtype=torch.float32, device=device)
+    """The root Camera's cam[16] (identity o2w, look_at (0,0,1)); one upload per device."""
+    t = _default_cams.get(str(device))
+    if t is None:
+        t = torch.tensor(_IDENT_CAM, dtype=torch.float32, device=device)
+        _default_cams[str(device)] = t
+    return t
 
 
 def render(w2o, material, light, kinds=None, cam=None, *, x_dims, y_dims, antialias_samples=4,

@@ -20,6 +20,9 @@ from .transform import RayField, Transform
 from .util import *        # noqa: F401,F403
 
 
+_kinds_cache = {}
+
+
 class Scene(object):
     def __init__(self, shapes, lights, camera, shader):
         self.shapes = shapes
@@ -36,7 +39,11 @@ class Scene(object):
         if S:
             w2o = torch.stack([s.w2o.m[:3, :] for s in self.shapes])
             material = torch.stack([s.material.as_row() for s in self.shapes])
-            kinds = torch.as_tensor(np.array([s.kind for s in self.shapes], dtype=np.uint8), device=dev)
+            key = (tuple(s.kind for s in self.shapes), str(dev))
+            kinds = _kinds_cache.get(key)          # module-level: drivers rebuild their Scene every step
+            if kinds is None:
+                kinds = torch.as_tensor(np.array(key[0], dtype=np.uint8), device=dev)
+                _kinds_cache[key] = kinds
         else:
             w2o = torch.zeros(0, 3, 4, dtype=floatX, device=dev)
             material = torch.zeros(0, 7, dtype=floatX, device=dev)
@@ -90,6 +97,7 @@ class Camera(object):
         self.look_at = np.asarray([0, 0, 1.0], dtype="float32") if camera_dir is None \
             else np.asarray(camera_dir, dtype="float32")
         self.rays = None
+        self._row = None
 
     @property
     def transpose(self):
@@ -102,12 +110,16 @@ class Camera(object):
     def as_row(self):
         """cam[16] of include/rrt.h: rows 0..2 of o2w.m, look_at, pad."""
         dev = device()
+        if self._row is not None and self._row[0] == str(dev):
+            return self._row[1]          # cameras are not differentiated: built once (also keeps H2D copies out of graphs)
         if self.o2w is None:
             m = torch.eye(4, dtype=floatX, device=dev)[:3, :]
         else:
             m = self.o2w.m[:3, :].detach().to(dev)
         look = torch.as_tensor(self.look_at, dtype=floatX, device=dev)
-        return torch.cat([m.reshape(-1), look, torch.zeros(1, dtype=floatX, device=dev)])
+        row = torch.cat([m.reshape(-1), look, torch.zeros(1, dtype=floatX, device=dev)])
+        self._row = (str(dev), row)
+        return row
 
     def make_rays(self, x_dims, y_dims, sampleDist_x=None, sampleDist_y=None):
         """scene.py:61-75 (NumPy, float64 then cast) -> RayField.  API parity

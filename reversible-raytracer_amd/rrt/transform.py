@@ -52,22 +52,55 @@ class Transform(object):
 
 def identity():
     """transform.py:56-58"""
-    return Transform(torch.eye(4, dtype=floatX, device=device()), torch.eye(4, dtype=floatX, device=device()))
+    return Transform(_eye(device()).clone(), _eye(device()).clone())
+
+
+_consts = {}
+
+
+def _const(name, dev, make):
+    """Constant helper tensors, built once per device (on the host, one upload):
+    element writes like ``t[3, 3] = 1`` are host-to-device copies, which a HIP
+    graph capture of the step does not allow."""
+    key = (name, str(dev))
+    t = _consts.get(key)
+    if t is None:
+        t = make().to(dev)
+        _consts[key] = t
+    return t
+
+
+def _basis(positions, dev):
+    def make():
+        b = torch.zeros(len(positions), 4, 4, dtype=floatX)
+        for n, (r, c) in enumerate(positions):
+            b[n, r, c] = 1.0
+        return b
+    return _const(("basis",) + tuple(positions), dev, make)
+
+
+def _last(dev):
+    def make():
+        t = torch.zeros(4, 4, dtype=floatX)
+        t[3, 3] = 1.0
+        return t
+    return _const("last", dev, make)
+
+
+def _eye(dev):
+    return _const("eye", dev, lambda: torch.eye(4, dtype=floatX))
 
 
 def _place(vals, positions):
     """4x4 matrix with vals[n] at positions[n] (functional set_subtensor chain)."""
     dev = vals[0].device
-    basis = torch.zeros(len(vals), 4, 4, dtype=floatX, device=dev)
-    for n, (r, c) in enumerate(positions):
-        basis[n, r, c] = 1.0
-    return (torch.stack(list(vals)).view(-1, 1, 1) * basis).sum(0)
+    return (torch.stack(list(vals)).view(-1, 1, 1) * _basis(tuple(positions), dev)).sum(0)
 
 
 def translate(x):
     """transform.py:60-75"""
     x = as_tensor_variable(x)
-    eye = torch.eye(4, dtype=floatX, device=x.device)
+    eye = _eye(x.device)
     pos = [(0, 3), (1, 3), (2, 3)]
     off = _place([x[0], x[1], x[2]], pos)
     return Transform(eye + off, eye - off)
@@ -76,8 +109,7 @@ def translate(x):
 def scale(x):
     """transform.py:78-93 (inverse uses 1./x)"""
     x = as_tensor_variable(x)
-    last = torch.zeros(4, 4, dtype=floatX, device=x.device)
-    last[3, 3] = 1.0
+    last = _last(x.device)
     pos = [(0, 0), (1, 1), (2, 2)]
     m = _place([x[0], x[1], x[2]], pos) + last
     mInv = _place([1.0 / x[0], 1.0 / x[1], 1.0 / x[2]], pos) + last
@@ -103,7 +135,5 @@ def rotate(angle, axis):
         a[2] * a[2] + (1.0 - a[2] * a[2]) * c,
     ]
     pos = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2)]
-    last = torch.zeros(4, 4, dtype=floatX, device=angle.device)
-    last[3, 3] = 1.0
-    m = _place(vals, pos) + last
+    m = _place(vals, pos) + _last(angle.device)
     return Transform(m, m.T)

@@ -419,3 +419,34 @@ def test_example_planet_orbit_writes_reference_layout(dev, tmp_path):
     assert d.shape == (6, 2, 64, 64, 3) and d.dtype == np.uint8
     # the fixed red sphere (0,0,48) x 6 is visible in every frame; the two cameras differ
     assert (d[..., 0] > 100).any() and not np.array_equal(d[:, 0], d[:, 1])
+
+
+def test_graphed_gradient_descent_matches_eager(dev):
+    """GDOptimizer(graph=True): the whole step captured in a HIP graph gives the
+    same trajectory as the eager step (same kernels, same order)."""
+    import rrt
+    from rrt import Camera, GDOptimizer, Light, Material, PhongShader, Scene, Sphere, Square, rotate, shared, translate
+    rrt.set_device(dev)
+
+    def run(graph):
+        c1 = shared(np.asarray([-.5, -.5, 4], dtype="float32"))
+        c2 = shared(np.asarray([.5, .5, 4], dtype="float32"))
+        m1 = Material((0.2, 0.9, 0.4), 0.3, 0.7, 0.5, 50.)
+        m2 = Material((0.87, 0.1, 0.507), 0.3, 0.9, 0.4, 50.)
+        light = Light((-1., -1., 2.), (1., 0.87, 0.961))
+        cam = Camera(128, 128)
+
+        def build():
+            objs = [Sphere(translate(c1), m1), Sphere(translate(c2), m2),
+                    Square(translate((0, 0, 3)) * rotate(50, [0., 1., 0.]), m2)]
+            return Scene(objs, [light], cam, PhongShader()).build(jitter=17)
+        flipped = torch.flip(build().detach(), dims=[1])
+        cost = lambda: ((build() - flipped) ** 2).sum()
+        train = GDOptimizer().optimize([c1, c2], cost, 0.000008, 0.1, graph=graph)
+        losses = [train() for _ in range(8)]
+        return losses, c1.detach().cpu().numpy(), c2.detach().cpu().numpy()
+
+    le, c1e, c2e = run(False)
+    lg, c1g, c2g = run(True)
+    assert lg[-1] < lg[0]
+    assert np.allclose(le, lg, rtol=1e-3) and np.allclose(c1e, c1g, atol=1e-4) and np.allclose(c2e, c2g, atol=1e-4)

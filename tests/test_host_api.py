@@ -210,3 +210,34 @@ def test_dataset_writers_use_the_reference_layout(tmp_path):
     back = dataset.load_dataset(str(tmp_path / "orbit.npz"))                     # test_optimization.py:56-57
     assert back.dtype == np.float32 and np.allclose(back, o / 255.0)
     assert np.load(str(tmp_path / "orbit_target.npz"))["arr_0"].shape == (2, 3)
+
+
+def test_constant_cache_returns_the_same_tensor_and_never_aliases_variables():
+    from rrt import config
+    a = config.as_tensor_variable((0, 0, 3))
+    b = config.as_tensor_variable((0.0, 0.0, 3.0))
+    assert a is b and a.tolist() == [0.0, 0.0, 3.0]
+    s1, s2 = config.as_tensor_variable(2.0), config.as_tensor_variable(2)
+    assert s1 is s2 and s1.dim() == 0
+    v = shared(np.array([0., 0., 3.]))
+    assert config.as_tensor_variable(v) is v                 # variables pass through, never cached
+    t1 = translate((0, 0, 3))
+    t2 = translate((0, 0, 3))
+    assert torch.equal(t1.m, t2.m) and t1.m is not t2.m      # fresh matrices from cached constants
+
+
+def test_batched_front_end_matches_transform_objects():
+    from rrt import batched
+    rs = np.random.RandomState(0)
+    c = torch.tensor(rs.randn(5, 3), dtype=torch.float32, requires_grad=True)
+    r = torch.tensor(rs.uniform(.2, 2., (5, 3)), dtype=torch.float32)
+    w = batched.w2o_translate_scale(c, r)
+    for k in range(5):
+        t = translate(c[k].detach()) * scale(r[k])
+        assert torch.allclose(w[k], t.inverse().m[:3, :], atol=1e-6)
+    wu = batched.w2o_translate_scale(c, r[:, 0])
+    assert torch.allclose(wu[2], (translate(c[2].detach()) * scale(r[2, 0].repeat(3))).inverse().m[:3, :], atol=1e-6)
+    (g,) = torch.autograd.grad(w.sum(), c)
+    assert g.shape == (5, 3) and torch.isfinite(g).all()
+    m = batched.materials(rs.rand(5, 3), 0.3, torch.full((5,), 0.7), 0.5, 50.)
+    assert m.shape == (5, 7) and torch.allclose(m[:, 3], torch.full((5,), 0.3)) and float(m[0, 6]) == 50.
