@@ -486,7 +486,7 @@ RRT_HD void pack_shape(const float* w2o, const float* cam, const float* mat, con
   float sh = mat[6];
   if (sh == floorf(sh) && fabsf(sh) < 16777216.0f) {
     powf |= POW_INT;
-    if (fmodf(fabsf(sh), 2.0f) == 1.0f) powf |= POW_ODD;
+    if (((int)fabsf(sh)) & 1) powf |= POW_ODD;
   } else if (fabsf(sh) >= 16777216.0f && sh == sh) {
     powf |= POW_INT;   // every float this large is an even integer
   }
