@@ -159,6 +159,43 @@ def cpu_baseline(size, spheres, aa, rows):
                       % (row0, row0 + rows, size, size, spheres, dt)}
 
 
+def parity_sample(dev, size, spheres, aa, rows=48):
+    """max|d grad| of the HIP path vs the float64 oracle (the second half of
+    BASELINE.json's metric) on a band of the benchmark workload: the oracle's
+    array-at-a-time autograd cannot do the whole 4096^2 image in bench time.
+    The oracle is used here as the checker only."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import rrt
+    import rrt_oracle as O
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(spheres, seed=0)
+    row0 = max(0, size // 2 - rows // 2)
+    rows = min(rows, size - row0)
+    G = np.random.RandomState(1).randn(rows, size, 3)
+    tw = torch.tensor(w2o, device=dev, requires_grad=True)
+    tm = torch.tensor(mat, device=dev, requires_grad=True)
+    tl = torch.tensor(light, device=dev, requires_grad=True)
+    img = rrt.render(tw, tm, tl, kinds, x_dims=size, y_dims=size, antialias_samples=aa, jitter="center",
+                     row0=row0, rows=rows)
+    (img * torch.tensor(G, dtype=torch.float32, device=dev)).sum().backward()
+    torch.cuda.synchronize()
+    oi, ow, om, ol = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=size, y_dims=size,
+                                        antialias_samples=aa, row0=row0, rows=rows)
+    di = (img.detach().cpu().double() - oi).abs().amax(-1)
+
+    def stats(a, b):
+        d = (a.detach().cpu().double() - b).abs().max().item()
+        return d, d / max(b.abs().max().item(), 1e-30)
+    aw, rw = stats(tw.grad, ow)
+    am, rm = stats(tm.grad[:, :6], om[:, :6])
+    al, rl = stats(tl.grad, ol)
+    return {"sample": "rows [%d,%d) of the workload, white-noise upstream gradient, vs the float64 CPU oracle"
+                      % (row0, row0 + rows),
+            "max_abs_dimage": di.max().item(), "pixels_off_by_more_than_2e-4": int((di > 2e-4).sum().item()),
+            "max_abs_dgrad": {"w2o": aw, "material": am, "light": al},
+            "max_rel_dgrad": {"w2o": rw, "material": rm, "light": rl}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,8 +295,10 @@ def main():
 
     if rank == 0:
         cpu = None
+        parity = None
         if world == 1 and args.cpu_rows > 0 and args.workload == "c4":
             cpu = cpu_baseline(args.size, args.spheres, args.aa, args.cpu_rows)
+            parity = parity_sample(dev, args.size, args.spheres, args.aa)
         out = {
             "metric": "Mrays/s fwd+bwd at %dx%d/%d spheres" % (args.size, args.size, args.spheres),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,7 +313,7 @@ def main():
                                     "c5": "config 5: 256 orbit scenes (2 spheres, stereo cameras, no specular), 64x64, "
                                           "antialias_samples=4, one batched launch"}[args.workload],
                        "cull": not args.no_cull, "parallelism": "rowband%d" % world},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out))
     if use_dist:
