@@ -3,17 +3,17 @@
 // Kernels of one forward/backward pair (DESIGN.md section 5 has the full story
 // and the measurements behind every choice):
 //
-//   k_setup     one thread per (scene, shape): fold the camera into the shape
-//               transform, precompute per-shape constants and a camera-local
-//               bounding ball (one 128-B record per shape), zero the shape's
-//               gradient-accumulator row and the tile-list counters.
-//   k_bin       workgroup = a 4 x 64 block of wave tiles (a tile is 64 x P
-//               pixels): two-level cone-vs-ball cull -> a candidate bit mask per
-//               tile; packed tile entries are appended to a "has candidates"
-//               and a "none" list with one packed atomic per workgroup.
+//   k_prep      workgroup = a 4 x 64 block of wave tiles (a tile is 64 x P
+//               pixels) of one scene.  Its threads pack the scene's shapes (fold
+//               the camera into the transform, per-shape constants, camera-local
+//               bounding ball; the scene's first workgroup stores the 128-B
+//               records and zeroes the gradient-accumulator rows), then run a
+//               two-level cone-vs-ball cull -> a candidate bit mask per tile;
+//               packed tile entries go to the workgroup's own segment of a "has
+//               candidates" and a "none" list (no atomics, nothing pre-zeroed).
 //   k_fwd<P>    persistent; one WAVE per tile, one lane per pixel column, P rows
-//               per lane.  List entries arrive 64 at a time (one per lane,
-//               v_readlane); the packed scene is staged in LDS once and a
+//               per lane.  A workgroup scan of the segment sizes deals list
+//               entries gw, gw + n_waves, ... to wave gw; the packed scene is staged in LDS once and a
 //               shape's record reaches SGPRs by one ds_read_b32 + v_readlane
 //               (scalar loads through the constant address space when the scene
 //               is too big); rays are generated in registers; winners are
@@ -21,7 +21,7 @@
 //               global_store_dwordx3 (a wave row is 768 contiguous bytes).
 //               Tiles without candidates are only zero-filled.
 //   k_bwd<P>    persistent, one 1024-thread workgroup per CU with an LDS work
-//               queue; tiles without candidates never touch the upstream
+//               queue (filled the same way); tiles without candidates never touch the upstream
 //               gradient; the next tile's gradient rows are requested before
 //               the current tile's arithmetic.  For every candidate shape that
 //               won somewhere in the wave, the lanes it won run the analytic
@@ -49,6 +49,8 @@ using namespace rrt;
 constexpr int TILE_W = 64;      // one lane per pixel column: a wave row is 768 contiguous bytes
 constexpr int WAVES = 16;       // waves per k_bwd workgroup: ONE 1024-thread workgroup fills a CU at the
 constexpr int BLOCK = WAVES * 64;   // kernel's 4 waves/SIMD, so its LDS work queue balances the whole CU
+// k_prep: wave tiles per workgroup (= threads) and list slots per segment
+constexpr int BIN_RX = 4, BIN_RY = 64, SEG = BIN_RX * BIN_RY;
 constexpr int WAVES_F = 4;      // waves per k_fwd workgroup (statically dealt tiles: no coupling wanted)
 constexpr int BLOCK_F = WAVES_F * 64;
 constexpr int MAX_WORDS = RRT_MAX_SHAPES / 64;
@@ -101,7 +103,8 @@ struct KArgs {
   const unsigned long long* heavy; // [n_tiles] packed entries of tiles with >= 1 candidate (first counts[0])
   const unsigned long long* empty; // [n_tiles] packed entries of tiles with none           (first counts[1])
   int lds_scene;                  // 1: B*S packed records fit the kernels' LDS staging area
-  const unsigned* counts;         // [4]
+  const unsigned* blk_counts;     // [n_bins] per prep-block: #entries in its "has candidates" segment | #"none" << 16
+  int n_bins;                     // prep workgroups = list segments of SEG slots
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
@@ -145,139 +148,6 @@ __device__ __forceinline__ Tile decode_tile(const KArgs& a, long long tile) {
   t.nrows = min(a.P, a.v.rows - t.a0);
   t.ncols = min(TILE_W, a.v.ncols - t.b0);
   return t;
-}
-
-// ------------------------------------------------------------------ setup --
-__global__ void k_setup(int S, int B, const float* w2o, long long w2o_bs, const float* mat, long long mat_bs,
-                        const float* light, const uint8_t* kind, const float* cam, long long cam_bs,
-                        float* ps, float* hdr, float* acc, unsigned* counts) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < 4) counts[idx] = 0u;
-  if (idx < B * S) {
-    int b = idx / S, k = idx - b * S;
-    pack_shape<float, float>(w2o + b * w2o_bs + 12 * k, cam + b * cam_bs, mat + b * mat_bs + 7 * k, light,
-                             kind ? (int)kind[k] : 0, ps + (size_t)idx * PS_STRIDE);
-    float4* row = reinterpret_cast<float4*>(acc + (size_t)idx * ACC_STRIDE);
-    for (int q = 0; q < ACC_STRIDE / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (idx < B) pack_header<float, float>(cam + idx * cam_bs, light, hdr + (size_t)idx * HDR_STRIDE);
-}
-
-// -------------------------------------------------------------------- bin --
-// Candidate shapes per tile.  A shape is dropped only when no line through the
-// camera origin inside the tile's direction cone can touch its bounding ball.
-// Two levels: a workgroup owns a BIN_RX x BIN_RY block of tiles (about square
-// in pixels); its threads first cull the scene's shapes against the whole
-// region (one shape per lane, ballot-compacted into LDS in list order), then
-// every thread tests its own tile against the survivors only.  Finally the
-// tile ids are appended to the "has candidates" / "none" lists with ONE packed
-// 64-bit atomic per workgroup (a same-address atomic costs ~12 ns, so per-wave
-// appends would serialise into tens of microseconds).
-constexpr int BIN_RX = 4, BIN_RY = 64;          // 4*64 tiles = 256 threads; 256 x 64P pixels
-__global__ __launch_bounds__(256) void k_bin(KArgs a, unsigned long long* mask_out, unsigned long long* heavy_out,
-                                             unsigned long long* empty_out, unsigned long long* counts) {
-  __shared__ float4 s_ball[RRT_MAX_SHAPES];     // surviving shapes' bounding balls, list order
-  __shared__ unsigned short s_id[RRT_MAX_SHAPES];
-  __shared__ int s_wave_n[4];
-  __shared__ int s_n;
-  __shared__ unsigned s_base[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bx_n = (a.tiles_x + BIN_RX - 1) / BIN_RX, by_n = (a.tiles_y + BIN_RY - 1) / BIN_RY;
-  int blk = blockIdx.x;
-  const int bx = blk % bx_n; blk /= bx_n;
-  const int by = blk % by_n;
-  const int b = blk / by_n;
-  const int tx = bx * BIN_RX + (tid & (BIN_RX - 1)), ty = by * BIN_RY + (tid / BIN_RX);
-  const bool valid = tx < a.tiles_x && ty < a.tiles_y;
-  const long long tile = ((long long)b * a.tiles_y + ty) * a.tiles_x + tx;
-  const bool nocull = (a.v.flags & RRT_FLAG_NO_CULL) != 0;
-  const float* ps = a.ps + (size_t)b * a.S * PS_STRIDE;
-
-  // level 1: region cone vs every shape
-  Cone<float> region;
-  {
-    int ra0 = by * BIN_RY * a.P, ra1 = min((by + 1) * BIN_RY * a.P, a.v.rows) - 1;
-    int rb0 = bx * BIN_RX * TILE_W, rb1 = min((bx + 1) * BIN_RX * TILE_W, a.v.ncols) - 1;
-    int i0, j0, i1, j1;
-    pixel_to_ray(a.v, ra0 + a.v.row0, rb0, i0, j0);
-    pixel_to_ray(a.v, ra1 + a.v.row0, rb1, i1, j1);
-    region = tile_cone<float>(a.v, i0, i1, j0, j1);
-  }
-  int n = 0;                                     // survivors so far (uniform)
-  for (int k0 = 0; k0 < a.S; k0 += 256) {
-    const int k = k0 + tid;
-    float4 ball = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool c = false;
-    if (k < a.S) {
-      ball = *reinterpret_cast<const float4*>(ps + (size_t)k * PS_STRIDE + PS_CULL_C);
-      float cc[3] = {ball.x, ball.y, ball.z};
-      c = nocull || cone_may_hit<float>(region, cc, ball.w);
-    }
-    unsigned long long bal = __ballot(c);
-    if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bal);
-    __syncthreads();
-    int off = n;
-    for (int w = 0; w < wave; ++w) off += s_wave_n[w];
-    if (c) {
-      int slot = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-      s_ball[slot] = ball;
-      s_id[slot] = (unsigned short)k;
-    }
-    n += s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
-    __syncthreads();
-  }
-
-  // level 2: this thread's tile vs the survivors (ascending shape id)
-  bool any = false;
-  int k_first = 0, n_cand = 0;
-  if (valid) {
-    Tile t;
-    t.b = b; t.a0 = ty * a.P; t.b0 = tx * TILE_W;
-    t.nrows = min(a.P, a.v.rows - t.a0); t.ncols = min(TILE_W, a.v.ncols - t.b0);
-    int i0, j0, i1, j1;
-    pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
-    pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
-    Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
-    unsigned long long m = 0;
-    int cur = 0;                                 // mask word being assembled
-    for (int q = 0; q < n; ++q) {
-      const int k = s_id[q];
-      const int w = k >> 6;
-      while (cur < w) { mask_out[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
-      bool c = true;
-      if (!nocull) {
-        float4 ball = s_ball[q];
-        float cc[3] = {ball.x, ball.y, ball.z};
-        c = cone_may_hit<float>(cone, cc, ball.w);
-      }
-      m |= (unsigned long long)c << (k & 63);
-      if (c) { if (!n_cand) k_first = k; ++n_cand; }
-    }
-    while (cur < a.nwords) { mask_out[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
-  }
-
-  // append to the two lists: one packed atomic per workgroup
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const unsigned long long bh = __ballot(valid && any), be = __ballot(valid && !any);
-  if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bh) | (__builtin_popcountll(be) << 16);
-  __syncthreads();
-  int pre_h = 0, pre_e = 0, tot_h = 0, tot_e = 0;
-  for (int w = 0; w < 4; ++w) {
-    int h = s_wave_n[w] & 0xffff, e = s_wave_n[w] >> 16;
-    if (w < wave) { pre_h += h; pre_e += e; }
-    tot_h += h; tot_e += e;
-  }
-  if (tid == 0) {
-    unsigned long long old = atomicAdd(counts, (unsigned long long)tot_h | ((unsigned long long)tot_e << 32));
-    s_base[0] = (unsigned)old;
-    s_base[1] = (unsigned)(old >> 32);
-  }
-  __syncthreads();
-  if (valid) {
-    const unsigned long long e = encode_entry(tx, ty, b, k_first, n_cand > 1);
-    if (any) heavy_out[s_base[0] + pre_h + __builtin_popcountll(bh & lt)] = e;
-    else empty_out[s_base[1] + pre_e + __builtin_popcountll(be & lt)] = e;
-  }
 }
 
 // ---------------------------------------------------------------- helpers --
@@ -385,6 +255,150 @@ __device__ __forceinline__ int global_wave(int& lane) {
   return (int)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 }
 
+// ------------------------------------------------------------------- prep --
+// ONE launch prepares everything the render kernels read from the workspace.
+// A workgroup owns a BIN_RX x BIN_RY block of wave tiles of one scene (about
+// square in pixels: 256 x 64P):
+//   1. every thread packs one shape of the scene (camera folded into the
+//      transform, per-shape constants, camera-local bounding ball); the block
+//      that owns the scene's first tiles also writes the 128-B records, the
+//      scene header and zeroed accumulator rows to the workspace;
+//   2. level-1 cull: the same thread tests its shape against the REGION's ray
+//      cone; survivors are ballot-compacted into LDS in list order;
+//   3. level-2 cull: every thread tests its own TILE against the survivors ->
+//      64-bit candidate masks;
+//   4. the tile entries (column, row, scene, first candidate, "several" bit)
+//      are compacted into the block's own 256-slot segment of the "has
+//      candidates" and the "none" list; the block's two counts go to blk_counts.
+// No global atomics and nothing that needs pre-zeroing: consumers walk the
+// segments (slot s of block s>>8 is valid iff (s & 255) < count).  A shape is
+// dropped only when no line through the camera origin inside the tile's
+// direction cone can touch its bounding ball.
+struct PrepArgs {
+  const float* w2o; long long w2o_bs;
+  const float* mat; long long mat_bs;
+  const float* light;
+  const uint8_t* kind;
+  const float* cam; long long cam_bs;
+  float* ps; float* hdr; float* acc;
+  unsigned long long* mask; unsigned long long* heavy; unsigned long long* empty;
+  unsigned* blk_counts;
+};
+
+__global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
+  __shared__ float4 s_ball[RRT_MAX_SHAPES];     // surviving shapes' bounding balls, list order
+  __shared__ unsigned short s_id[RRT_MAX_SHAPES];
+  __shared__ int s_wave_n[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx_n = (a.tiles_x + BIN_RX - 1) / BIN_RX, by_n = (a.tiles_y + BIN_RY - 1) / BIN_RY;
+  int blk = blockIdx.x;
+  const int bx = blk % bx_n; blk /= bx_n;
+  const int by = blk % by_n;
+  const int b = blk / by_n;
+  const bool owner = bx == 0 && by == 0;        // writes scene b's records
+  const int tx = bx * BIN_RX + (tid & (BIN_RX - 1)), ty = by * BIN_RY + (tid / BIN_RX);
+  const bool valid = tx < a.tiles_x && ty < a.tiles_y;
+  const long long tile = ((long long)b * a.tiles_y + ty) * a.tiles_x + tx;
+  const bool nocull = (a.v.flags & RRT_FLAG_NO_CULL) != 0;
+  const float* cam = pa.cam + b * pa.cam_bs;
+
+  Cone<float> region;
+  {
+    int ra0 = by * BIN_RY * a.P, ra1 = min((by + 1) * BIN_RY * a.P, a.v.rows) - 1;
+    int rb0 = bx * BIN_RX * TILE_W, rb1 = min((bx + 1) * BIN_RX * TILE_W, a.v.ncols) - 1;
+    int i0, j0, i1, j1;
+    pixel_to_ray(a.v, ra0 + a.v.row0, rb0, i0, j0);
+    pixel_to_ray(a.v, ra1 + a.v.row0, rb1, i1, j1);
+    region = tile_cone<float>(a.v, i0, i1, j0, j1);
+  }
+  if (owner && tid == 0) pack_header<float, float>(cam, pa.light, pa.hdr + (size_t)b * HDR_STRIDE);
+
+  int n = 0;                                     // survivors so far (uniform)
+  for (int k0 = 0; k0 < a.S; k0 += 256) {
+    const int k = k0 + tid;
+    float4 ball = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool c = false;
+    if (k < a.S) {
+      float rec[PS_STRIDE];
+      pack_shape<float, float>(pa.w2o + b * pa.w2o_bs + 12 * k, cam, pa.mat + b * pa.mat_bs + 7 * k, pa.light,
+                               pa.kind ? (int)pa.kind[k] : 0, rec);
+      ball = make_float4(rec[PS_CULL_C], rec[PS_CULL_C + 1], rec[PS_CULL_C + 2], rec[PS_CULL_R]);
+      if (owner) {
+        float4* dst = reinterpret_cast<float4*>(pa.ps + ((size_t)b * a.S + k) * PS_STRIDE);
+        float4* row = reinterpret_cast<float4*>(pa.acc + ((size_t)b * a.S + k) * ACC_STRIDE);
+#pragma unroll
+        for (int q = 0; q < PS_STRIDE / 4; ++q) {
+          dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+          row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      float cc[3] = {ball.x, ball.y, ball.z};
+      c = nocull || cone_may_hit<float>(region, cc, ball.w);
+    }
+    unsigned long long bal = __ballot(c);
+    if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int off = n;
+    for (int w = 0; w < wave; ++w) off += s_wave_n[w];
+    if (c) {
+      int slot = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      s_ball[slot] = ball;
+      s_id[slot] = (unsigned short)k;
+    }
+    n += s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
+    __syncthreads();
+  }
+
+  // level 2: this thread's tile vs the survivors (ascending shape id)
+  bool any = false;
+  int k_first = 0, n_cand = 0;
+  if (valid) {
+    Tile t;
+    t.b = b; t.a0 = ty * a.P; t.b0 = tx * TILE_W;
+    t.nrows = min(a.P, a.v.rows - t.a0); t.ncols = min(TILE_W, a.v.ncols - t.b0);
+    int i0, j0, i1, j1;
+    pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
+    pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
+    Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
+    unsigned long long m = 0;
+    int cur = 0;                                 // mask word being assembled
+    for (int q = 0; q < n; ++q) {
+      const int k = s_id[q];
+      const int w = k >> 6;
+      while (cur < w) { pa.mask[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
+      bool c = true;
+      if (!nocull) {
+        float4 ball = s_ball[q];
+        float cc[3] = {ball.x, ball.y, ball.z};
+        c = cone_may_hit<float>(cone, cc, ball.w);
+      }
+      m |= (unsigned long long)c << (k & 63);
+      if (c) { if (!n_cand) k_first = k; ++n_cand; }
+    }
+    while (cur < a.nwords) { pa.mask[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
+  }
+
+  // compact the tile entries into this block's own list segments
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long bh = __ballot(valid && any), be = __ballot(valid && !any);
+  __syncthreads();                               // s_wave_n is reused
+  if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bh) | (__builtin_popcountll(be) << 16);
+  __syncthreads();
+  int pre_h = 0, pre_e = 0, tot_h = 0, tot_e = 0;
+  for (int w = 0; w < 4; ++w) {
+    int h = s_wave_n[w] & 0xffff, e = s_wave_n[w] >> 16;
+    if (w < wave) { pre_h += h; pre_e += e; }
+    tot_h += h; tot_e += e;
+  }
+  if (tid == 0) pa.blk_counts[blockIdx.x] = (unsigned)tot_h | ((unsigned)tot_e << 16);
+  if (valid) {
+    const unsigned long long e = encode_entry(tx, ty, b, k_first, n_cand > 1);
+    const size_t seg = (size_t)blockIdx.x * SEG;
+    if (any) pa.heavy[seg + pre_h + __builtin_popcountll(bh & lt)] = e;
+    else pa.empty[seg + pre_e + __builtin_popcountll(be & lt)] = e;
+  }
+}
+
 // ---- per-workgroup work queue ------------------------------------------------
 // Workgroup wg owns entries wg, wg + n_wgs, ... of a tile list (a fair, spatially
 // interleaved share).  They are copied into LDS once and handed to the
@@ -392,21 +406,88 @@ __device__ __forceinline__ int global_wave(int& lane) {
 // atomics): a tile costs 1x..3x depending on its candidates and coverage, and a
 // static deal per WAVE left most SIMDs idle behind the unluckiest wave
 // (profiles/: 2.6 of 4 resident waves busy on average).
-constexpr int Q_CAP = 1024;            // entries staged per batch
+constexpr int Q_CAP = 1024;            // entries staged per batch (k_bwd workgroup)
+constexpr int W_CAP = 64;              // entries per batch and wave (k_fwd): one per lane
 struct WgQueue {
   unsigned long long ent[Q_CAP];
+  unsigned scan[2 * WAVES];
+  unsigned ex[Q_CAP];              // exclusive prefix of the chunk's segment sizes
   unsigned cursor;
 };
 
-// All 1024 threads: stage batch `batch` of this workgroup's share; returns its size.
-__device__ __forceinline__ unsigned queue_fill(WgQueue& q, const unsigned long long* list, unsigned n, unsigned batch) {
-  const unsigned share = n > blockIdx.x ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  const unsigned lo = batch * Q_CAP;
-  const unsigned cnt = share > lo ? min((unsigned)Q_CAP, share - lo) : 0;
-  __syncthreads();                                   // previous batch fully consumed
-  for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x)
-    q.ent[i] = list[(size_t)blockIdx.x + (size_t)(lo + i) * gridDim.x];
-  if (threadIdx.x == 0) q.cursor = 0;
+// Inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside each row of 16
+// (row_shr 1, 2, 4, 8), then row totals forwarded with row_bcast:15 / row_bcast:31.  Lanes a
+// DPP control does not reach add 0.  Six VALU adds, no LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_add_u32(unsigned x) {
+  return x + (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
+  x = dpp_add_u32<0x111, 0xf>(x);   // row_shr:1
+  x = dpp_add_u32<0x112, 0xf>(x);   // row_shr:2
+  x = dpp_add_u32<0x114, 0xf>(x);   // row_shr:4
+  x = dpp_add_u32<0x118, 0xf>(x);   // row_shr:8
+  x = dpp_add_u32<0x142, 0xa>(x);   // row_bcast:15 into rows 1,3
+  x = dpp_add_u32<0x143, 0xc>(x);   // row_bcast:31 into rows 2,3
+  return x;
+}
+
+// Exclusive prefix sums of (x, y) over the workgroup's NW*64 threads, and the grand totals
+// (wave-uniform).  One barrier; s_w[2*NW] must not be in use.
+template <int NW>
+__device__ __forceinline__ void block_excl_scan2(unsigned x, unsigned y, unsigned* s_w, int lane, int wave,
+                                                 unsigned& ex, unsigned& ey, unsigned& tot_x, unsigned& tot_y) {
+  const unsigned ix = wave_incl_scan(x), iy = wave_incl_scan(y);
+  if (lane == 63) { s_w[2 * wave] = ix; s_w[2 * wave + 1] = iy; }
+  __syncthreads();
+  unsigned ox = 0, oy = 0;
+  tot_x = tot_y = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const unsigned tx = s_w[2 * w], ty = s_w[2 * w + 1];
+    if (w < wave) { ox += tx; oy += ty; }
+    tot_x += tx; tot_y += ty;
+  }
+  tot_x = __builtin_amdgcn_readfirstlane(tot_x);
+  tot_y = __builtin_amdgcn_readfirstlane(tot_y);
+  ex = ox + ix - x;
+  ey = oy + iy - y;
+}
+
+// Entry number x of a chunk's (virtual) concatenated list -> its slot in the segmented list.
+// s_ex = exclusive prefix of the chunk's nb segment sizes; the segment is the last one that
+// starts at or before x (branch-free binary search, TOP = half the chunk capacity).
+template <int TOP>
+__device__ __forceinline__ size_t chunk_slot(const unsigned* s_ex, unsigned bin0, unsigned nb, unsigned x) {
+  unsigned lo = 0;
+#pragma unroll
+  for (unsigned step = TOP; step; step >>= 1) {
+    const unsigned i = lo + step;
+    if (s_ex[min(i, nb - 1)] <= x && i < nb) lo = i;
+  }
+  return (size_t)(bin0 + lo) * SEG + (x - s_ex[lo]);
+}
+
+// All 1024 threads: k_prep left every block's entries in the block's own segment.  Thread t
+// brings c = the size of segment bin0 + t of the chunk [bin0, bin0 + nb); a workgroup scan gives
+// each entry its index in the (virtual) concatenated list, of which the workgroup owns
+// blockIdx.x, + gridDim.x, ...: `next` is its first index not yet staged, `base` the number
+// of entries before the chunk (both updated).  Returns the number staged (<= Q_CAP: the
+// caller sizes the chunk for that).
+__device__ __forceinline__ unsigned queue_fill(WgQueue& q, const unsigned long long* list, unsigned c, unsigned bin0,
+                                               unsigned nb, unsigned& base, unsigned& next, int lane, int wave) {
+  const unsigned t = threadIdx.x;
+  unsigned ex, ey, total, ty;
+  block_excl_scan2<WAVES>(c, 0u, q.scan, lane, wave, ex, ey, total, ty);
+  q.ex[t] = ex;
+  if (t == 0) q.cursor = 0;
+  __syncthreads();
+  const unsigned end = base + total;
+  const unsigned g = next + t * gridDim.x;
+  if (g < end) q.ent[t] = list[chunk_slot<Q_CAP / 2>(q.ex, bin0, nb, g - base)];
+  const unsigned cnt = next < end ? (end - next + gridDim.x - 1) / gridDim.x : 0u;
+  next += cnt * gridDim.x;
+  base = end;
   __syncthreads();
   return cnt;
 }
@@ -426,38 +507,38 @@ __device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, un
 #define RRT_BWD_WAVES_PER_SIMD 1
 #endif
 #ifndef RRT_FWD_WAVES_PER_SIMD
-#define RRT_FWD_WAVES_PER_SIMD 1
+#define RRT_FWD_WAVES_PER_SIMD 4
 #endif
 
 // ---------------------------------------------------------------- forward --
 // Persistent.  Wave gw takes entries gw, gw + n_waves, ... of the "has
 // candidates" list and of the "none" list (concurrent waves touch adjacent
-// tiles; every wave sees a fair mix of cheap and expensive tiles).  Its
-// entries are fetched 64 at a time, one per lane, and broadcast with
-// v_readlane; rendered tiles alternate with the wave's share of zero-filled
+// tiles; every wave sees a fair mix of cheap and expensive tiles).  The
+// lists live in k_prep's per-block segments: a workgroup scan of the segment
+// sizes plus a binary search per lane fetch the wave's entries 64 at a time,
+// one per lane, and v_readlane broadcasts them; rendered tiles alternate with the wave's share of zero-filled
 // tiles so the store stream runs under the arithmetic.
 template <int P, int SHADER, int SPEC>
 __global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
+  __shared__ unsigned s_scan[2 * WAVES_F];
+  __shared__ unsigned s_exh[BLOCK_F], s_exe[BLOCK_F];   // exclusive prefixes of the chunk's segment sizes
   const ViewK& v = a.v;
   int lane;
   const int gw = global_wave<WAVES_F>(lane);
-  stage_scene(a, s_scene);
-  const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
-  const unsigned n_empty = ((const __attribute__((address_space(4))) unsigned*)a.counts)[1];
-  const unsigned hcount = n_heavy > (unsigned)gw ? (n_heavy - gw + a.n_waves - 1) / a.n_waves : 0;
-  const unsigned ecount = n_empty > (unsigned)gw ? (n_empty - gw + a.n_waves - 1) / a.n_waves : 0;
-  const unsigned per = hcount ? (ecount + hcount - 1) / hcount : 0;
+  const int wave = gw - (int)blockIdx.x * WAVES_F;
+  const unsigned nw = (unsigned)a.n_waves;
+  // chunk of list segments per pass: one per thread, and at most 64 entries per wave and list
+  const unsigned chunk = min((unsigned)BLOCK_F, max(1u, W_CAP * nw / SEG));
+  unsigned cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? a.blk_counts[threadIdx.x] : 0u;   // in flight under
+  stage_scene(a, s_scene);                                                                        // the staging
 
-  unsigned long long ebatch = 0;       // empty-list entries, one per lane
-  unsigned ebase = 0, epos = 0;        // positions within this wave's share
+  unsigned long long hent = 0, eent = 0;   // this wave's entries of the current chunk, one per lane
+  unsigned ecount = 0, epos = 0;
   auto zero_fill = [&](unsigned count) {
     for (unsigned n = 0; n < count && epos < ecount; ++n, ++epos) {
-      if (epos == ebase)
-        ebatch = (ebase + lane < ecount) ? a.empty[(size_t)gw + (size_t)(ebase + lane) * a.n_waves] : 0ull;
       int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, lane_bcast64(ebatch, (int)(epos - ebase)), k0, multi, tile);
-      if (epos + 1 == ebase + 64) ebase += 64;
+      const Tile t = decode_entry(a, lane_bcast64(eent, (int)epos), k0, multi, tile);
       if (lane < t.ncols) {
         const F3 zero = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -473,14 +554,45 @@ __global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a
 
   int b_cur = -1;
   float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
-  for (unsigned base = 0; base < hcount; base += 64) {
-    const unsigned long long hbatch =
-        (base + lane < hcount) ? a.heavy[(size_t)gw + (size_t)(base + lane) * a.n_waves] : 0ull;
-    const int nb = (int)min(64u, hcount - base);
-    for (int it = 0; it < nb; ++it) {
+  unsigned base_h = 0, base_e = 0;         // entries before the chunk
+  unsigned next_h = gw, next_e = gw;       // this wave's first index not yet taken
+  for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
+    const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
+    if (bin0) {
+      __syncthreads();                     // previous chunk's prefixes consumed
+      cw = threadIdx.x < nb ? a.blk_counts[bin0 + threadIdx.x] : 0u;
+    }
+    unsigned tot_h, tot_e;
+    block_excl_scan2<WAVES_F>(cw & 0xffffu, cw >> 16, s_scan, lane, wave, s_exh[threadIdx.x], s_exe[threadIdx.x],
+                              tot_h, tot_e);
+    __syncthreads();
+    const unsigned end_h = base_h + tot_h, end_e = base_e + tot_e;
+    const unsigned gh = next_h + lane * nw, ge = next_e + lane * nw;
+    {
+      // both binary searches side by side (their LDS reads overlap), then the two loads
+      const unsigned xh = gh < end_h ? gh - base_h : 0u, xe = ge < end_e ? ge - base_e : 0u;
+      unsigned lh = 0, le = 0;
+#pragma unroll
+      for (unsigned step = BLOCK_F / 2; step; step >>= 1) {
+        const unsigned ih = lh + step, ie = le + step;
+        const unsigned vh = s_exh[min(ih, nb - 1)], ve = s_exe[min(ie, nb - 1)];
+        if (vh <= xh && ih < nb) lh = ih;
+        if (ve <= xe && ie < nb) le = ie;
+      }
+      const unsigned oh = xh - s_exh[lh], oe = xe - s_exe[le];
+      hent = gh < end_h ? a.heavy[(size_t)(bin0 + lh) * SEG + oh] : 0ull;
+      eent = ge < end_e ? a.empty[(size_t)(bin0 + le) * SEG + oe] : 0ull;
+    }
+    const unsigned hcount = __builtin_popcountll(__ballot(gh < end_h));
+    ecount = __builtin_popcountll(__ballot(ge < end_e));
+    epos = 0;
+    next_h += hcount * nw; next_e += ecount * nw;
+    base_h = end_h; base_e = end_e;
+    const unsigned per = hcount ? (ecount + hcount - 1) / hcount : 0;
+    for (unsigned it = 0; it < hcount; ++it) {
       zero_fill(per);
       int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, lane_bcast64(hbatch, it), k0, multi, tile);
+      const Tile t = decode_entry(a, lane_bcast64(hent, (int)it), k0, multi, tile);
       if (t.b != b_cur) {
         cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
         for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
@@ -568,8 +680,8 @@ __global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a
         }
       }
     }
+    zero_fill(0xffffffffu);
   }
-  zero_fill(0xffffffffu);
 }
 
 // --------------------------------------------------------------- backward --
@@ -624,12 +736,12 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   int lane;
   global_wave<WAVES>(lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // chunk of list segments per batch: one per thread, and no more than Q_CAP entries for this workgroup
+  const unsigned chunk = min((unsigned)BLOCK, max(1u, Q_CAP * gridDim.x / SEG));
+  unsigned cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? (a.blk_counts[threadIdx.x] & 0xffffu) : 0u;
   if (a.lds_scene)
     for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
   stage_scene(a, s_scene);          // ends with the workgroup barrier
-  const unsigned n_heavy = ((const __attribute__((address_space(4))) unsigned*)a.counts)[0];
-  const unsigned wg_share = n_heavy > blockIdx.x ? (n_heavy - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-
   int b_cur = -1;
   float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
   // (only when the scene does not fit the LDS accumulators) the last global accumulator
@@ -640,8 +752,14 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   int held_k = 0, held_b = 0;
   float held_val = 0.f;
 
-  for (unsigned batch = 0; batch * Q_CAP < wg_share; ++batch) {
-    const unsigned cnt = queue_fill(s_q, a.heavy, n_heavy, batch);
+  unsigned base = 0, next = blockIdx.x;
+  for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
+    const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
+    if (bin0) {
+      __syncthreads();                     // previous batch fully consumed
+      cw = threadIdx.x < nb ? (a.blk_counts[bin0 + threadIdx.x] & 0xffffu) : 0u;
+    }
+    const unsigned cnt = queue_fill(s_q, a.heavy, cw, bin0, nb, base, next, lane, wave);
     unsigned long long e_cur = 0, e_nxt = 0;
     bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
     F3 g[P];
@@ -855,7 +973,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Geometry {
   int P, ncols, nwords, tiles_x, tiles_y;
-  long long n_tiles;
+  long long n_tiles, n_bins;
   size_t ps_off, hdr_off, acc_off, counts_off, mask_off, heavy_off, empty_off, total;
 };
 
@@ -886,11 +1004,12 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.ps_off = 0;
   g.hdr_off = g.ps_off + n_shapes * PS_STRIDE * sizeof(float);
   g.acc_off = g.hdr_off + (size_t)s->B * HDR_STRIDE * sizeof(float);
+  g.n_bins = (long long)((g.tiles_x + BIN_RX - 1) / BIN_RX) * ((g.tiles_y + BIN_RY - 1) / BIN_RY) * s->B;
   g.counts_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
-  g.mask_off = g.counts_off + 16;
+  g.mask_off = align_up(g.counts_off + (size_t)g.n_bins * sizeof(unsigned), 16);
   g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
-  g.empty_off = align_up(g.heavy_off + (size_t)g.n_tiles * sizeof(unsigned long long), 16);
-  g.total = align_up(g.empty_off + (size_t)g.n_tiles * sizeof(unsigned long long) + 16, 16);
+  g.empty_off = g.heavy_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long);
+  g.total = align_up(g.empty_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long), 16);
   return g;
 }
 
@@ -946,7 +1065,8 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.heavy = (const unsigned long long*)(base + g.heavy_off);
   a.empty = (const unsigned long long*)(base + g.empty_off);
   a.lds_scene = ((long long)s->B * s->S <= LDS_RECS && !getenv("RRT_TUNE_NOLDS")) ? 1 : 0;
-  a.counts = (const unsigned*)(base + g.counts_off);
+  a.blk_counts = (const unsigned*)(base + g.counts_off);
+  a.n_bins = (int)g.n_bins;
   a.n_waves = 0;
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
   a.image = nullptr;
@@ -954,24 +1074,22 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   return a;
 }
 
-// k_setup + k_bin: everything the render kernels read from the workspace.
+// k_prep: everything the render kernels read from the workspace.
 int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStream_t st) {
-  int n = s->B * s->S > s->B ? s->B * s->S : s->B;
-  hipLaunchKernelGGL(k_setup, dim3((n + 255) / 256), dim3(256), 0, st, s->S, s->B, s->w2o,
-                     (long long)s->w2o_bstride, s->material, (long long)s->material_bstride, s->light, s->kind,
-                     v->cam, (long long)v->cam_bstride, const_cast<float*>(a.ps), const_cast<float*>(a.hdr), a.acc,
-                     const_cast<unsigned*>(a.counts));
+  if (a.n_bins <= 0) return RRT_OK;
+  PrepArgs pa;
+  pa.w2o = s->w2o; pa.w2o_bs = (long long)s->w2o_bstride;
+  pa.mat = s->material; pa.mat_bs = (long long)s->material_bstride;
+  pa.light = s->light; pa.kind = s->kind;
+  pa.cam = v->cam; pa.cam_bs = (long long)v->cam_bstride;
+  pa.ps = const_cast<float*>(a.ps); pa.hdr = const_cast<float*>(a.hdr); pa.acc = a.acc;
+  pa.mask = const_cast<unsigned long long*>(a.mask);
+  pa.heavy = const_cast<unsigned long long*>(a.heavy);
+  pa.empty = const_cast<unsigned long long*>(a.empty);
+  pa.blk_counts = const_cast<unsigned*>(a.blk_counts);
+  hipLaunchKernelGGL(k_prep, dim3((unsigned)a.n_bins), dim3(256), 0, st, a, pa);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e);
-  if (a.n_tiles > 0) {
-    long long bins = (long long)((a.tiles_x + BIN_RX - 1) / BIN_RX) * ((a.tiles_y + BIN_RY - 1) / BIN_RY) * a.B;
-    hipLaunchKernelGGL(k_bin, dim3((unsigned)bins), dim3(256), 0, st, a,
-                       const_cast<unsigned long long*>(a.mask), const_cast<unsigned long long*>(a.heavy),
-                       const_cast<unsigned long long*>(a.empty),
-                       reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(a.counts)));
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e);
-  }
   return RRT_OK;
 }
 
@@ -1101,7 +1219,16 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
     if (rc != RRT_OK) return rc;
   }
   hipError_t e;
-  if (g.n_tiles > 0 && s->S > 0) {
+  if (g.n_tiles == 0) {
+    // an empty band (a rank with no rows): nothing was prepared, the gradients are zero
+    size_t n_shapes = (size_t)s->B * (size_t)s->S;
+    e = hipSuccess;
+    if (g_w2o && n_shapes) e = hipMemsetAsync(g_w2o, 0, n_shapes * 12 * sizeof(float), st);
+    if (e == hipSuccess && g_material && n_shapes) e = hipMemsetAsync(g_material, 0, n_shapes * 7 * sizeof(float), st);
+    if (e == hipSuccess && g_light) e = hipMemsetAsync(g_light, 0, 6 * sizeof(float), st);
+    return e == hipSuccess ? RRT_OK : hip_fail(e);
+  }
+  if (s->S > 0) {
     unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 1));
     a.n_waves = (int)blocks * WAVES;
     if (g.P == 4) launch_bwd<4>(a, blocks, a.v.shader, a.v.specular, st);
