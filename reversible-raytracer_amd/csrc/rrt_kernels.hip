@@ -704,6 +704,32 @@ __device__ __forceinline__ float wave_sum_to_lane63(float x) {
   return x;
 }
 
+// acc[0..21] (per-lane partial sums, all 64 lanes active) -> r6: row j (lanes 16j..16j+15) of
+// r6[m], m < 5, ends with total m + {0, 6, 11, 17}[j] in its last lane; r6[5] with total 5 in
+// lane 15 and total 16 in lane 47.
+__device__ __forceinline__ void wave_sums_22(const float acc[ACC_USED], float r6[6]) {
+  static_assert(ACC_USED == 22, "the butterfly is laid out for 22 values");
+  float r[11];
+#pragma unroll
+  for (int n = 0; n < 11; ++n) {
+    // rows 2,3 of acc[n] <-> rows 0,1 of acc[n+11]: the sum folds lane i onto lane i^32,
+    // value n in the lower half of the wave, value n+11 in the upper
+    auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[n]), __float_as_uint(acc[n + 11]), false, false);
+    r[n] = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);
+  }
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    // odd rows of r[m] <-> even rows of r[m+6]: rows 0,2 keep r[m]'s two values, rows 1,3 get r[m+6]'s
+    auto pr = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[m]), __float_as_uint(r[m < 5 ? m + 6 : m]), false, false);
+    float x = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);
+    x = dpp_add<0xb1, 0xf>(x);    // quad_perm:[1,0,3,2]
+    x = dpp_add<0x4e, 0xf>(x);    // quad_perm:[2,3,0,1]
+    x = dpp_add<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);   // row_shr:8 -> the row's total in its last lane
+    r6[m] = x;
+  }
+}
+
 template <int P>
 __device__ __forceinline__ void load_grad_rows(const KArgs& a, const Tile& t, int lane, F3 g[P]) {
 #pragma unroll
@@ -868,17 +894,29 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
           }
           RRT_STAMP(4);
           if (!__ballot(anyhit)) continue;
-          // 22 wave sums -> lane n holds value n -> one 22-lane atomic
-          float mine_val = 0.f;
-#pragma unroll
-          for (int n = 0; n < ACC_USED; ++n) {
-            float tot = wave_sum_to_lane63(acc[n]);
-            float bc = lane_bcast(tot, 63);
-            mine_val = (lane == n) ? bc : mine_val;
-          }
+          // 22 per-lane partial sums -> 22 totals, as a transposing butterfly: a swap + an add
+          // folds TWO values across half the wave (v_permlane32_swap), then across rows
+          // (v_permlane16_swap); the six survivors carry four values each (one per 16-lane row)
+          // and finish with four DPP adds -- 59 VALU ops instead of 22 full wave sums (176)
+          float r6[6];
+          wave_sums_22(acc, r6);
           if (a.lds_scene) {
-            if (lane < ACC_USED) atomicAdd(&s_acc[((size_t)t.b * a.S + k) * ACC_STRIDE + lane], mine_val);
+            // row j of r6[m] holds total m + {0,6,11,17}[j] in its last lane (r6[5]: rows 0 and 2 only)
+            float* row = &s_acc[((size_t)t.b * a.S + k) * ACC_STRIDE + (lane >> 4) * 6 - (lane >> 5)];
+            if ((lane & 15) == 15) {
+#pragma unroll
+              for (int m = 0; m < 5; ++m) atomicAdd(row + m, r6[m]);
+              if (!(lane & 16)) atomicAdd(row + 5, r6[5]);
+            }
           } else {
+            float mine_val = 0.f;
+#pragma unroll
+            for (int n = 0; n < ACC_USED; ++n) {
+              const int m = n < 6 ? n : (n < 11 ? n - 6 : (n < 16 ? n - 11 : (n == 16 ? 5 : n - 17)));
+              const int j = n < 6 ? 0 : (n < 11 ? 1 : (n < 17 ? 2 : 3));
+              const float bc = lane_bcast(r6[m], 16 * j + 15);
+              mine_val = (lane == n) ? bc : mine_val;
+            }
             if (held && lane < ACC_USED)
               __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val,
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
