@@ -103,7 +103,8 @@ struct KArgs {
   const unsigned long long* heavy; // [n_tiles] packed entries of tiles with >= 1 candidate (first counts[0])
   const unsigned long long* empty; // [n_tiles] packed entries of tiles with none           (first counts[1])
   int lds_scene;                  // 1: B*S packed records fit the kernels' LDS staging area
-  const unsigned* blk_counts;     // [n_bins] per prep-block: #entries in its "has candidates" segment | #"none" << 16
+  const unsigned* blk_counts;     // [n_bins][2] per prep-block: #tiles with 3+ candidates | 2 candidates << 16,
+                                  //             1 candidate | none << 16
   int n_bins;                     // prep workgroups = list segments of SEG slots
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
@@ -378,24 +379,40 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
     while (cur < a.nwords) { pa.mask[tile * a.nwords + cur] = m; any |= (m != 0); m = 0; ++cur; }
   }
 
-  // compact the tile entries into this block's own list segments
+  // compact the tile entries into this block's own list segments.  The "has candidates"
+  // segment is ordered by cost class -- 3+ candidates, 2, 1 -- so that consumers can deal and
+  // schedule by class (class 3 = no candidate -> the "none" segment)
+  const int cls = !valid ? 4 : (n_cand >= 3 ? 0 : (n_cand == 2 ? 1 : (n_cand == 1 ? 2 : 3)));
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const unsigned long long bh = __ballot(valid && any), be = __ballot(valid && !any);
-  __syncthreads();                               // s_wave_n is reused
-  if (lane == 0) s_wave_n[wave] = __builtin_popcountll(bh) | (__builtin_popcountll(be) << 16);
-  __syncthreads();
-  int pre_h = 0, pre_e = 0, tot_h = 0, tot_e = 0;
-  for (int w = 0; w < 4; ++w) {
-    int h = s_wave_n[w] & 0xffff, e = s_wave_n[w] >> 16;
-    if (w < wave) { pre_h += h; pre_e += e; }
-    tot_h += h; tot_e += e;
+  unsigned long long mine = 0;                   // ballot of this thread's class
+  unsigned long long wave_n = 0;                 // 4 x 16 bit: this wave's count per class
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long bal = __ballot(cls == c);
+    if (cls == c) mine = bal;
+    wave_n |= (unsigned long long)__builtin_popcountll(bal) << (16 * c);
   }
-  if (tid == 0) pa.blk_counts[blockIdx.x] = (unsigned)tot_h | ((unsigned)tot_e << 16);
+  __shared__ unsigned long long s_cls_n[4];
+  if (lane == 0) s_cls_n[wave] = wave_n;
+  __syncthreads();
+  unsigned long long pre = 0, tot = 0;           // 4 x 16 bit: earlier waves / whole block
+  for (int w = 0; w < 4; ++w) {
+    const unsigned long long x = s_cls_n[w];
+    if (w < wave) pre += x;
+    tot += x;
+  }
+  const unsigned n0 = (unsigned)tot & 0xffffu, n1 = (unsigned)(tot >> 16) & 0xffffu, n2 = (unsigned)(tot >> 32) & 0xffffu,
+                 n3 = (unsigned)(tot >> 48);
+  if (tid == 0) {
+    pa.blk_counts[2 * blockIdx.x] = n0 | (n1 << 16);
+    pa.blk_counts[2 * blockIdx.x + 1] = n2 | (n3 << 16);
+  }
   if (valid) {
     const unsigned long long e = encode_entry(tx, ty, b, k_first, n_cand > 1);
     const size_t seg = (size_t)blockIdx.x * SEG;
-    if (any) pa.heavy[seg + pre_h + __builtin_popcountll(bh & lt)] = e;
-    else pa.empty[seg + pre_e + __builtin_popcountll(be & lt)] = e;
+    const unsigned rank = ((unsigned)(pre >> (16 * cls)) & 0xffffu) + __builtin_popcountll(mine & lt);
+    const unsigned start = cls == 0 ? 0u : (cls == 1 ? n0 : (cls == 2 ? n0 + n1 : 0u));
+    (cls == 3 ? pa.empty : pa.heavy)[seg + start + rank] = e;
   }
 }
 
@@ -410,8 +427,9 @@ constexpr int Q_CAP = 1024;            // entries staged per batch (k_bwd workgr
 constexpr int W_CAP = 64;              // entries per batch and wave (k_fwd): one per lane
 struct WgQueue {
   unsigned long long ent[Q_CAP];
-  unsigned scan[2 * WAVES];
-  unsigned ex[Q_CAP];              // exclusive prefix of the chunk's segment sizes
+  unsigned scan[3 * WAVES];
+  unsigned ex[3][Q_CAP];           // per cost class: exclusive prefix of the chunk's segment sizes
+  unsigned cnt01[Q_CAP];           // segment sizes of classes 0 and 1 (16 bits each)
   unsigned cursor;
 };
 
@@ -432,59 +450,67 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
   return x;
 }
 
-// Exclusive prefix sums of (x, y) over the workgroup's NW*64 threads, and the grand totals
-// (wave-uniform).  One barrier; s_w[2*NW] must not be in use.
-template <int NW>
-__device__ __forceinline__ void block_excl_scan2(unsigned x, unsigned y, unsigned* s_w, int lane, int wave,
-                                                 unsigned& ex, unsigned& ey, unsigned& tot_x, unsigned& tot_y) {
-  const unsigned ix = wave_incl_scan(x), iy = wave_incl_scan(y);
-  if (lane == 63) { s_w[2 * wave] = ix; s_w[2 * wave + 1] = iy; }
+// Exclusive prefix sums of N values per thread over the workgroup's NW*64 threads, and the
+// grand totals (wave-uniform).  One barrier; s_w[N*NW] must not be in use.
+template <int NW, int N>
+__device__ __forceinline__ void block_excl_scan(const unsigned (&x)[N], unsigned* s_w, int lane, int wave,
+                                                unsigned (&ex)[N], unsigned (&tot)[N]) {
+  unsigned incl[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    incl[n] = wave_incl_scan(x[n]);
+    if (lane == 63) s_w[N * wave + n] = incl[n];
+  }
   __syncthreads();
-  unsigned ox = 0, oy = 0;
-  tot_x = tot_y = 0;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    const unsigned tx = s_w[2 * w], ty = s_w[2 * w + 1];
-    if (w < wave) { ox += tx; oy += ty; }
-    tot_x += tx; tot_y += ty;
+  for (int n = 0; n < N; ++n) {
+    unsigned off = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned tw = s_w[N * w + n];
+      if (w < wave) off += tw;
+      t += tw;
+    }
+    tot[n] = __builtin_amdgcn_readfirstlane(t);
+    ex[n] = off + incl[n] - x[n];
   }
-  tot_x = __builtin_amdgcn_readfirstlane(tot_x);
-  tot_y = __builtin_amdgcn_readfirstlane(tot_y);
-  ex = ox + ix - x;
-  ey = oy + iy - y;
 }
 
-// Entry number x of a chunk's (virtual) concatenated list -> its slot in the segmented list.
-// s_ex = exclusive prefix of the chunk's nb segment sizes; the segment is the last one that
-// starts at or before x (branch-free binary search, TOP = half the chunk capacity).
-template <int TOP>
-__device__ __forceinline__ size_t chunk_slot(const unsigned* s_ex, unsigned bin0, unsigned nb, unsigned x) {
-  unsigned lo = 0;
-#pragma unroll
-  for (unsigned step = TOP; step; step >>= 1) {
-    const unsigned i = lo + step;
-    if (s_ex[min(i, nb - 1)] <= x && i < nb) lo = i;
-  }
-  return (size_t)(bin0 + lo) * SEG + (x - s_ex[lo]);
-}
-
-// All 1024 threads: k_prep left every block's entries in the block's own segment.  Thread t
-// brings c = the size of segment bin0 + t of the chunk [bin0, bin0 + nb); a workgroup scan gives
-// each entry its index in the (virtual) concatenated list, of which the workgroup owns
-// blockIdx.x, + gridDim.x, ...: `next` is its first index not yet staged, `base` the number
-// of entries before the chunk (both updated).  Returns the number staged (<= Q_CAP: the
-// caller sizes the chunk for that).
-__device__ __forceinline__ unsigned queue_fill(WgQueue& q, const unsigned long long* list, unsigned c, unsigned bin0,
+// All 1024 threads: k_prep left every block's entries in the block's own segment, ordered by
+// cost class (3+ candidates, 2, 1).  Thread t brings cw = the sizes of segment bin0 + t of the
+// chunk [bin0, bin0 + nb).  The chunk's (virtual) list is "every segment's class 0, then every
+// segment's class 1, then class 2": three workgroup scans give each entry its index in it, and
+// the workgroup owns the indices blockIdx.x, + gridDim.x, ... -- an equal share of every
+// class, staged expensive first (longest-processing-time-first inside the workgroup).
+// `next` is its first index not yet staged, `base` the number of entries before the chunk
+// (both updated).  Returns the number staged (<= Q_CAP: the caller sizes the chunk for that).
+__device__ __forceinline__ unsigned queue_fill(WgQueue& q, const unsigned long long* list, uint2 cw, unsigned bin0,
                                                unsigned nb, unsigned& base, unsigned& next, int lane, int wave) {
   const unsigned t = threadIdx.x;
-  unsigned ex, ey, total, ty;
-  block_excl_scan2<WAVES>(c, 0u, q.scan, lane, wave, ex, ey, total, ty);
-  q.ex[t] = ex;
+  const unsigned c3[3] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu};
+  unsigned ex[3], tot[3];
+  block_excl_scan<WAVES, 3>(c3, q.scan, lane, wave, ex, tot);
+  q.ex[0][t] = ex[0]; q.ex[1][t] = ex[1]; q.ex[2][t] = ex[2];
+  q.cnt01[t] = cw.x;
   if (t == 0) q.cursor = 0;
   __syncthreads();
-  const unsigned end = base + total;
+  const unsigned end = base + tot[0] + tot[1] + tot[2];
   const unsigned g = next + t * gridDim.x;
-  if (g < end) q.ent[t] = list[chunk_slot<Q_CAP / 2>(q.ex, bin0, nb, g - base)];
+  if (g < end) {
+    unsigned x = g - base;
+    const int cls = x < tot[0] ? 0 : (x < tot[0] + tot[1] ? 1 : 2);
+    x -= cls == 0 ? 0u : (cls == 1 ? tot[0] : tot[0] + tot[1]);
+    const unsigned* pre = q.ex[cls];
+    unsigned lo = 0;
+#pragma unroll
+    for (unsigned step = Q_CAP / 2; step; step >>= 1) {
+      const unsigned i = lo + step;
+      if (pre[min(i, nb - 1)] <= x && i < nb) lo = i;
+    }
+    const unsigned c01 = q.cnt01[lo];
+    const unsigned start = cls == 0 ? 0u : (cls == 1 ? (c01 & 0xffffu) : (c01 & 0xffffu) + (c01 >> 16));
+    q.ent[t] = list[(size_t)(bin0 + lo) * SEG + start + (x - pre[lo])];
+  }
   const unsigned cnt = next < end ? (end - next + gridDim.x - 1) / gridDim.x : 0u;
   next += cnt * gridDim.x;
   base = end;
@@ -530,8 +556,10 @@ __global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a
   const unsigned nw = (unsigned)a.n_waves;
   // chunk of list segments per pass: one per thread, and at most 64 entries per wave and list
   const unsigned chunk = min((unsigned)BLOCK_F, max(1u, W_CAP * nw / SEG));
-  unsigned cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? a.blk_counts[threadIdx.x] : 0u;   // in flight under
-  stage_scene(a, s_scene);                                                                        // the staging
+  // (the segment sizes are in flight under the staging)
+  uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
+                                                           : make_uint2(0u, 0u);
+  stage_scene(a, s_scene);
 
   unsigned long long hent = 0, eent = 0;   // this wave's entries of the current chunk, one per lane
   unsigned ecount = 0, epos = 0;
@@ -560,11 +588,14 @@ __global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a
     const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
     if (bin0) {
       __syncthreads();                     // previous chunk's prefixes consumed
-      cw = threadIdx.x < nb ? a.blk_counts[bin0 + threadIdx.x] : 0u;
+      cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
     }
-    unsigned tot_h, tot_e;
-    block_excl_scan2<WAVES_F>(cw & 0xffffu, cw >> 16, s_scan, lane, wave, s_exh[threadIdx.x], s_exe[threadIdx.x],
-                              tot_h, tot_e);
+    const unsigned cnt2[2] = {(cw.x & 0xffffu) + (cw.x >> 16) + (cw.y & 0xffffu), cw.y >> 16};
+    unsigned ex2[2], tot2[2];
+    block_excl_scan<WAVES_F, 2>(cnt2, s_scan, lane, wave, ex2, tot2);
+    s_exh[threadIdx.x] = ex2[0];
+    s_exe[threadIdx.x] = ex2[1];
+    const unsigned tot_h = tot2[0], tot_e = tot2[1];
     __syncthreads();
     const unsigned end_h = base_h + tot_h, end_e = base_e + tot_e;
     const unsigned gh = next_h + lane * nw, ge = next_e + lane * nw;
@@ -764,7 +795,8 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // chunk of list segments per batch: one per thread, and no more than Q_CAP entries for this workgroup
   const unsigned chunk = min((unsigned)BLOCK, max(1u, Q_CAP * gridDim.x / SEG));
-  unsigned cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? (a.blk_counts[threadIdx.x] & 0xffffu) : 0u;
+  uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
+                                                           : make_uint2(0u, 0u);
   if (a.lds_scene)
     for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
   stage_scene(a, s_scene);          // ends with the workgroup barrier
@@ -783,7 +815,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
     if (bin0) {
       __syncthreads();                     // previous batch fully consumed
-      cw = threadIdx.x < nb ? (a.blk_counts[bin0 + threadIdx.x] & 0xffffu) : 0u;
+      cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
     }
     const unsigned cnt = queue_fill(s_q, a.heavy, cw, bin0, nb, base, next, lane, wave);
     unsigned long long e_cur = 0, e_nxt = 0;
@@ -1044,7 +1076,7 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.acc_off = g.hdr_off + (size_t)s->B * HDR_STRIDE * sizeof(float);
   g.n_bins = (long long)((g.tiles_x + BIN_RX - 1) / BIN_RX) * ((g.tiles_y + BIN_RY - 1) / BIN_RY) * s->B;
   g.counts_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
-  g.mask_off = align_up(g.counts_off + (size_t)g.n_bins * sizeof(unsigned), 16);
+  g.mask_off = align_up(g.counts_off + (size_t)g.n_bins * 2 * sizeof(unsigned), 16);
   g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
   g.empty_off = g.heavy_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long);
   g.total = align_up(g.empty_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long), 16);

@@ -78,3 +78,18 @@ print("kernel span by s_memrealtime: %.1f us; sum of tile wave-times / span = %.
       ((t_last - t_first) / 100.0, (rt[ok].sum() / (t_last - t_first)) / 1024.0))
 single = h[:, 2] - h[:, 1] < 200
 print("single-candidate tiles: %d; their adjoint rows median %.0f cycles" % (single.sum(), np.median((h[:, 4] - h[:, 3])[single])))
+# busy-wave profile over the kernel span (tiles in flight per SIMD): ramp-up, plateau, tail
+t0 = h[ok, 7] - t_first
+t1 = h[ok, 2] - t_first
+span = t_last - t_first
+nb = 24
+edges = np.linspace(0, span, nb + 1)
+prof = []
+for i in range(nb):
+    lo, hi = edges[i], edges[i + 1]
+    ov = np.clip(np.minimum(t1, hi) - np.maximum(t0, lo), 0, None).sum() / (hi - lo)
+    prof.append(ov / 1024.0)
+print("busy waves per SIMD over %d slices of the span: %s" % (nb, " ".join("%.1f" % x for x in prof)))
+dur = (h[:, 2] - h[:, 7])[ok] / 100.0
+print("tile duration (us): median %.2f p10 %.2f p90 %.2f p99 %.2f max %.2f" % (
+    np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
