@@ -51,8 +51,6 @@ constexpr int WAVES = 16;       // waves per k_bwd workgroup: ONE 1024-thread wo
 constexpr int BLOCK = WAVES * 64;   // kernel's 4 waves/SIMD, so its LDS work queue balances the whole CU
 // k_prep: wave tiles per workgroup (= threads) and list slots per segment
 constexpr int BIN_RX = 4, BIN_RY = 64, SEG = BIN_RX * BIN_RY;
-constexpr int WAVES_F = 4;      // waves per k_fwd workgroup (statically dealt tiles: no coupling wanted)
-constexpr int BLOCK_F = WAVES_F * 64;
 constexpr int MAX_WORDS = RRT_MAX_SHAPES / 64;
 
 // Wave-uniform read-only data goes through the constant address space so the
@@ -85,9 +83,17 @@ __device__ unsigned long long* g_stamps = nullptr;   // [n_tiles][8]
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
     if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
   } while (0)
+// k_fwd: per-wave real-time stamps / counters in row `gw` (tools/stamp_fwd.py)
+#define RRT_STAMP_FWD(slot, value_or_rt)                                                    \
+  do {                                                                                      \
+    unsigned long long t_ = (value_or_rt);                                                  \
+    if (t_ == ~0ull) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    if (g_stamps && lane == 0) g_stamps[(size_t)gw * 8 + (slot)] = t_;                      \
+  } while (0)
 #else
 #define RRT_STAMP(slot) do {} while (0)
 #define RRT_STAMP_RT(slot) do {} while (0)
+#define RRT_STAMP_FWD(slot, value_or_rt) do {} while (0)
 #endif
 
 struct KArgs {
@@ -423,13 +429,18 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
 // atomics): a tile costs 1x..3x depending on its candidates and coverage, and a
 // static deal per WAVE left most SIMDs idle behind the unluckiest wave
 // (profiles/: 2.6 of 4 resident waves busy on average).
-constexpr int Q_CAP = 1024;            // entries staged per batch (k_bwd workgroup)
-constexpr int W_CAP = 64;              // entries per batch and wave (k_fwd): one per lane
+constexpr int Q_CAP = 1024;            // entries staged per batch and workgroup (= its threads)
 struct WgQueue {
   unsigned long long ent[Q_CAP];
-  unsigned scan[3 * WAVES];
+  unsigned scan[4 * WAVES];
   unsigned ex[3][Q_CAP];           // per cost class: exclusive prefix of the chunk's segment sizes
   unsigned cnt01[Q_CAP];           // segment sizes of classes 0 and 1 (16 bits each)
+  unsigned cursor;
+};
+// k_fwd only: the workgroup's share of the tiles without candidates (zero-filled)
+struct WgZeroQueue {
+  unsigned long long ent[Q_CAP];
+  unsigned ex[Q_CAP];
   unsigned cursor;
 };
 
@@ -450,29 +461,33 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
   return x;
 }
 
-// Exclusive prefix sums of N values per thread over the workgroup's NW*64 threads, and the
-// grand totals (wave-uniform).  One barrier; s_w[N*NW] must not be in use.
+// Exclusive prefix sums of N <= 4 values per thread over the workgroup's 16 waves, and the
+// grand totals (wave-uniform).  One barrier; s_w[N*16] must not be in use.  The 16 wave
+// totals of value n land in row n of ONE register (lane 16n + w), so the scan over waves is
+// four DPP adds and the results are picked with v_readlane -- a loop over LDS words here cost
+// 3 us of the kernels' prologue.
 template <int NW, int N>
 __device__ __forceinline__ void block_excl_scan(const unsigned (&x)[N], unsigned* s_w, int lane, int wave,
                                                 unsigned (&ex)[N], unsigned (&tot)[N]) {
+  static_assert(NW == 16 && N <= 4, "one 16-lane row per value");
   unsigned incl[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) {
     incl[n] = wave_incl_scan(x[n]);
-    if (lane == 63) s_w[N * wave + n] = incl[n];
+    if (lane == 63) s_w[16 * n + wave] = incl[n];
   }
   __syncthreads();
+  const unsigned own = lane < 16 * N ? s_w[lane] : 0u;
+  unsigned v = own;
+  v = dpp_add_u32<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_add_u32<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_add_u32<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add_u32<0x118, 0xf>(v);   // row_shr:8 -> inclusive over the waves, per row
+  const unsigned before = v - own;
 #pragma unroll
   for (int n = 0; n < N; ++n) {
-    unsigned off = 0, t = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const unsigned tw = s_w[N * w + n];
-      if (w < wave) off += tw;
-      t += tw;
-    }
-    tot[n] = __builtin_amdgcn_readfirstlane(t);
-    ex[n] = off + incl[n] - x[n];
+    tot[n] = (unsigned)__builtin_amdgcn_readlane((int)v, 16 * n + 15);
+    ex[n] = (unsigned)__builtin_amdgcn_readlane((int)before, 16 * n + wave) + incl[n] - x[n];
   }
 }
 
@@ -482,38 +497,68 @@ __device__ __forceinline__ void block_excl_scan(const unsigned (&x)[N], unsigned
 // segment's class 1, then class 2": three workgroup scans give each entry its index in it, and
 // the workgroup owns the indices blockIdx.x, + gridDim.x, ... -- an equal share of every
 // class, staged expensive first (longest-processing-time-first inside the workgroup).
-// `next` is its first index not yet staged, `base` the number of entries before the chunk
-// (both updated).  Returns the number staged (<= Q_CAP: the caller sizes the chunk for that).
-__device__ __forceinline__ unsigned queue_fill(WgQueue& q, const unsigned long long* list, uint2 cw, unsigned bin0,
-                                               unsigned nb, unsigned& base, unsigned& next, int lane, int wave) {
-  const unsigned t = threadIdx.x;
-  const unsigned c3[3] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu};
-  unsigned ex[3], tot[3];
-  block_excl_scan<WAVES, 3>(c3, q.scan, lane, wave, ex, tot);
+// QueueState carries the first index not yet staged and the number of entries before the
+// chunk.  Returns the number staged (<= Q_CAP: the caller sizes the chunk for that).  k_fwd
+// (WITH_EMPTY) stages its share of the "none" list the same way into the zero queue.
+struct QueueState {
+  unsigned base = 0, next = 0;       // "has candidates": entries before the chunk / first index not yet staged
+  unsigned base_e = 0, next_e = 0;   // "none" (k_fwd only)
+  unsigned cnt_e = 0;                // "none" entries staged in the current batch
+};
+
+template <bool WITH_EMPTY>
+__device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const unsigned long long* heavy,
+                                               const unsigned long long* empty, uint2 cw, unsigned bin0, unsigned nb,
+                                               QueueState& st, int lane, int wave) {
+  constexpr int N = WITH_EMPTY ? 4 : 3;
+  const unsigned t = threadIdx.x, n = gridDim.x;
+  unsigned c[N], ex[N], tot[N];
+  c[0] = cw.x & 0xffffu; c[1] = cw.x >> 16; c[2] = cw.y & 0xffffu;
+  if (WITH_EMPTY) c[N - 1] = cw.y >> 16;
+  block_excl_scan<WAVES, N>(c, q.scan, lane, wave, ex, tot);
   q.ex[0][t] = ex[0]; q.ex[1][t] = ex[1]; q.ex[2][t] = ex[2];
   q.cnt01[t] = cw.x;
-  if (t == 0) q.cursor = 0;
+  if (WITH_EMPTY) z->ex[t] = ex[N - 1];
+  if (t == 0) { q.cursor = 0; if (WITH_EMPTY) z->cursor = 0; }
   __syncthreads();
-  const unsigned end = base + tot[0] + tot[1] + tot[2];
-  const unsigned g = next + t * gridDim.x;
-  if (g < end) {
-    unsigned x = g - base;
+  { const int gw = blockIdx.x * WAVES + wave; (void)gw; RRT_STAMP_FWD(6, ~0ull); }
+  const unsigned end = st.base + tot[0] + tot[1] + tot[2];
+  const unsigned end_e = WITH_EMPTY ? st.base_e + tot[N - 1] : 0u;
+  const unsigned g = st.next + t * n, ge = st.next_e + t * n;
+  const bool on = g < end, on_e = WITH_EMPTY && ge < end_e;
+  if (__ballot(on || on_e)) {
+    unsigned x = on ? g - st.base : 0u;
     const int cls = x < tot[0] ? 0 : (x < tot[0] + tot[1] ? 1 : 2);
     x -= cls == 0 ? 0u : (cls == 1 ? tot[0] : tot[0] + tot[1]);
+    const unsigned xe = on_e ? ge - st.base_e : 0u;
     const unsigned* pre = q.ex[cls];
-    unsigned lo = 0;
+    unsigned lo = 0, le = 0;       // both binary searches side by side: their LDS reads overlap
 #pragma unroll
     for (unsigned step = Q_CAP / 2; step; step >>= 1) {
-      const unsigned i = lo + step;
-      if (pre[min(i, nb - 1)] <= x && i < nb) lo = i;
+      const unsigned i = lo + step, ie = le + step;
+      const unsigned pv = pre[min(i, nb - 1)];
+      if (WITH_EMPTY) {
+        const unsigned ev = z->ex[min(ie, nb - 1)];
+        if (ev <= xe && ie < nb) le = ie;
+      }
+      if (pv <= x && i < nb) lo = i;
     }
-    const unsigned c01 = q.cnt01[lo];
-    const unsigned start = cls == 0 ? 0u : (cls == 1 ? (c01 & 0xffffu) : (c01 & 0xffffu) + (c01 >> 16));
-    q.ent[t] = list[(size_t)(bin0 + lo) * SEG + start + (x - pre[lo])];
+    { const int gw = blockIdx.x * WAVES + wave; (void)gw; RRT_STAMP_FWD(7, ~0ull); }
+    if (on) {
+      const unsigned c01 = q.cnt01[lo];
+      const unsigned start = cls == 0 ? 0u : (cls == 1 ? (c01 & 0xffffu) : (c01 & 0xffffu) + (c01 >> 16));
+      q.ent[t] = heavy[(size_t)(bin0 + lo) * SEG + start + (x - pre[lo])];
+    }
+    if (on_e) z->ent[t] = empty[(size_t)(bin0 + le) * SEG + (xe - z->ex[le])];
   }
-  const unsigned cnt = next < end ? (end - next + gridDim.x - 1) / gridDim.x : 0u;
-  next += cnt * gridDim.x;
-  base = end;
+  const unsigned cnt = st.next < end ? (end - st.next + n - 1) / n : 0u;
+  st.next += cnt * n;
+  st.base = end;
+  if (WITH_EMPTY) {
+    st.cnt_e = st.next_e < end_e ? (end_e - st.next_e + n - 1) / n : 0u;
+    st.next_e += st.cnt_e * n;
+    st.base_e = end_e;
+  }
   __syncthreads();
   return cnt;
 }
@@ -537,93 +582,77 @@ __device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, un
 #endif
 
 // ---------------------------------------------------------------- forward --
-// Persistent.  Wave gw takes entries gw, gw + n_waves, ... of the "has
-// candidates" list and of the "none" list (concurrent waves touch adjacent
-// tiles; every wave sees a fair mix of cheap and expensive tiles).  The
-// lists live in k_prep's per-block segments: a workgroup scan of the segment
-// sizes plus a binary search per lane fetch the wave's entries 64 at a time,
-// one per lane, and v_readlane broadcasts them; rendered tiles alternate with the wave's share of zero-filled
-// tiles so the store stream runs under the arithmetic.
+// Persistent, one 1024-thread workgroup per CU.  The workgroup's share of the "has
+// candidates" list (an equal part of every cost class, expensive first) and of the "none"
+// list sit in two LDS queues; a wave pops a tile to render and, with it, its part of the
+// tiles to zero-fill, so the store stream runs under the arithmetic and no wave idles
+// behind an unlucky static deal (a wave timeline -- tools/stamp_fwd.py -- showed a third of
+// a statically dealt wave's life in the list prologue and an 11 us tail).
 template <int P, int SHADER, int SPEC>
-__global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
+__global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
-  __shared__ unsigned s_scan[2 * WAVES_F];
-  __shared__ unsigned s_exh[BLOCK_F], s_exe[BLOCK_F];   // exclusive prefixes of the chunk's segment sizes
+  __shared__ WgQueue s_q;
+  __shared__ WgZeroQueue s_z;
   const ViewK& v = a.v;
   int lane;
-  const int gw = global_wave<WAVES_F>(lane);
-  const int wave = gw - (int)blockIdx.x * WAVES_F;
-  const unsigned nw = (unsigned)a.n_waves;
-  // chunk of list segments per pass: one per thread, and at most 64 entries per wave and list
-  const unsigned chunk = min((unsigned)BLOCK_F, max(1u, W_CAP * nw / SEG));
+  const int gw = global_wave<WAVES>(lane);
+  const int wave = gw - (int)blockIdx.x * WAVES;
+  // chunk of list segments per batch: one per thread, and no more than Q_CAP tiles for this workgroup
+  const unsigned chunk = min((unsigned)BLOCK, max(1u, Q_CAP * gridDim.x / SEG));
+  RRT_STAMP_FWD(0, ~0ull);
   // (the segment sizes are in flight under the staging)
   uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
                                                            : make_uint2(0u, 0u);
   stage_scene(a, s_scene);
+  RRT_STAMP_FWD(5, ~0ull);
 
-  unsigned long long hent = 0, eent = 0;   // this wave's entries of the current chunk, one per lane
-  unsigned ecount = 0, epos = 0;
-  auto zero_fill = [&](unsigned count) {
-    for (unsigned n = 0; n < count && epos < ecount; ++n, ++epos) {
-      int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, lane_bcast64(eent, (int)epos), k0, multi, tile);
-      if (lane < t.ncols) {
-        const F3 zero = {0.f, 0.f, 0.f};
+  auto zero_tile = [&](unsigned long long e) {
+    int k0; bool multi; long long tile;
+    const Tile t = decode_entry(a, e, k0, multi, tile);
+    if (lane < t.ncols) {
+      const F3 zero = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          if (p < t.nrows) {
-            F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
-            out[lane] = zero;
-          }
+      for (int p = 0; p < P; ++p) {
+        if (p < t.nrows) {
+          F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+          out[lane] = zero;
         }
       }
     }
   };
+  // take `count` entries off the zero queue; false once it is exhausted
+  auto zero_fill = [&](unsigned count, unsigned cnt_e) {
+    unsigned i = 0;
+    if (lane == 0) i = atomicAdd(&s_z.cursor, count);
+    i = __builtin_amdgcn_readfirstlane(i);
+    const unsigned hi = min(i + count, cnt_e);
+    for (unsigned n = i; n < hi; ++n) zero_tile(lane_bcast64(s_z.ent[n], 0));
+    return i + count < cnt_e;
+  };
 
   int b_cur = -1;
   float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
-  unsigned base_h = 0, base_e = 0;         // entries before the chunk
-  unsigned next_h = gw, next_e = gw;       // this wave's first index not yet taken
+  QueueState qs;
+  qs.next = qs.next_e = blockIdx.x;
   for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
     const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
     if (bin0) {
-      __syncthreads();                     // previous chunk's prefixes consumed
+      __syncthreads();                     // previous batch fully consumed
       cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
     }
-    const unsigned cnt2[2] = {(cw.x & 0xffffu) + (cw.x >> 16) + (cw.y & 0xffffu), cw.y >> 16};
-    unsigned ex2[2], tot2[2];
-    block_excl_scan<WAVES_F, 2>(cnt2, s_scan, lane, wave, ex2, tot2);
-    s_exh[threadIdx.x] = ex2[0];
-    s_exe[threadIdx.x] = ex2[1];
-    const unsigned tot_h = tot2[0], tot_e = tot2[1];
-    __syncthreads();
-    const unsigned end_h = base_h + tot_h, end_e = base_e + tot_e;
-    const unsigned gh = next_h + lane * nw, ge = next_e + lane * nw;
-    {
-      // both binary searches side by side (their LDS reads overlap), then the two loads
-      const unsigned xh = gh < end_h ? gh - base_h : 0u, xe = ge < end_e ? ge - base_e : 0u;
-      unsigned lh = 0, le = 0;
-#pragma unroll
-      for (unsigned step = BLOCK_F / 2; step; step >>= 1) {
-        const unsigned ih = lh + step, ie = le + step;
-        const unsigned vh = s_exh[min(ih, nb - 1)], ve = s_exe[min(ie, nb - 1)];
-        if (vh <= xh && ih < nb) lh = ih;
-        if (ve <= xe && ie < nb) le = ie;
-      }
-      const unsigned oh = xh - s_exh[lh], oe = xe - s_exe[le];
-      hent = gh < end_h ? a.heavy[(size_t)(bin0 + lh) * SEG + oh] : 0ull;
-      eent = ge < end_e ? a.empty[(size_t)(bin0 + le) * SEG + oe] : 0ull;
-    }
-    const unsigned hcount = __builtin_popcountll(__ballot(gh < end_h));
-    ecount = __builtin_popcountll(__ballot(ge < end_e));
-    epos = 0;
-    next_h += hcount * nw; next_e += ecount * nw;
-    base_h = end_h; base_e = end_e;
-    const unsigned per = hcount ? (ecount + hcount - 1) / hcount : 0;
-    for (unsigned it = 0; it < hcount; ++it) {
-      zero_fill(per);
+    const unsigned cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave);
+    const unsigned cnt_e = qs.cnt_e;
+    const unsigned per = cnt ? (cnt_e + cnt - 1) / cnt : 0;
+    RRT_STAMP_FWD(1, ~0ull);
+    unsigned long long e_cur;
+    bool more_zero = cnt_e > 0;
+    // (a counted loop with a break: as `while (pop)` hipcc needed 13 more VGPRs and spilled)
+#pragma unroll 1
+    for (unsigned it = 0; it < cnt; ++it) {
+      if (!queue_pop(s_q, cnt, lane, e_cur)) break;
+      if (more_zero) more_zero = zero_fill(per, cnt_e);
       int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, lane_bcast64(hent, (int)it), k0, multi, tile);
+      const Tile t = decode_entry(a, e_cur, k0, multi, tile);
       if (t.b != b_cur) {
         cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
         for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
@@ -699,20 +728,24 @@ __global__ __launch_bounds__(BLOCK_F, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a
           }
         }
       }
-      // one dwordx3 per lane and row: the wave writes 768 contiguous bytes
+      // one dwordx3 per lane and row: the wave writes 768 contiguous bytes.  (The empty asm
+      // keeps the address arithmetic down here: hoisted above the sample loop it was spilled.)
+      int a0 = t.a0, b0 = t.b0;
+      asm volatile("" : "+s"(a0), "+s"(b0));
       if (lane < t.ncols) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (p < t.nrows) {
-            F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
+            F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + a0 + p) * v.ncols + b0) * 3);
             F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
             out[lane] = val;
           }
         }
       }
     }
-    zero_fill(0xffffffffu);
+    while (more_zero) more_zero = zero_fill(2, cnt_e);
   }
+  RRT_STAMP_FWD(2, ~0ull);
 }
 
 // --------------------------------------------------------------- backward --
@@ -810,14 +843,15 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   int held_k = 0, held_b = 0;
   float held_val = 0.f;
 
-  unsigned base = 0, next = blockIdx.x;
+  QueueState qs;
+  qs.next = blockIdx.x;
   for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
     const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
     if (bin0) {
       __syncthreads();                     // previous batch fully consumed
       cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
     }
-    const unsigned cnt = queue_fill(s_q, a.heavy, cw, bin0, nb, base, next, lane, wave);
+    const unsigned cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave);
     unsigned long long e_cur = 0, e_nxt = 0;
     bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
     F3 g[P];
@@ -1186,9 +1220,9 @@ unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
 
 template <int P>
 void launch_fwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
-  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK_F), 0, st, a);
-  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK_F), 0, st, a);
-  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK_F), 0, st, a);
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
 }
 
 template <int P>
@@ -1262,10 +1296,8 @@ int rrt_render_fwd(const rrt_scene* s, const rrt_view* v, float* image_out, void
     if (rc != RRT_OK) return rc;
   }
   if (g.n_tiles == 0) return RRT_OK;
-  long long want = (long long)device_cus() * tuned_wgs("RRT_TUNE_FWD_WGS", 8);
-  long long need = (g.n_tiles + WAVES_F - 1) / WAVES_F;
-  unsigned blocks = (unsigned)(want < need ? want : need);
-  a.n_waves = (int)blocks * WAVES_F;
+  unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_FWD_WGS", 1));
+  a.n_waves = (int)blocks * WAVES;
   if (g.P == 4) launch_fwd<4>(a, blocks, a.v.shader, a.v.specular, st);
   else if (g.P == 2) launch_fwd<2>(a, blocks, a.v.shader, a.v.specular, st);
   else launch_fwd<1>(a, blocks, a.v.shader, a.v.specular, st);

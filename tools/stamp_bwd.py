@@ -18,7 +18,7 @@ OUT = os.path.join(REPO, "gpurun_out", "librrt_hip_stamps.so")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                        "-DRRT_STAMPS", "-fno-slp-vectorize", "-I", os.path.join(REPO, "include"), "-I", os.path.join(PKG, "csrc"),
-                       os.path.join(PKG, "csrc", "rrt_kernels.hip"), "-o", OUT])
+                       os.environ.get("RRT_STAMP_SRC", os.path.join(PKG, "csrc", "rrt_kernels.hip")), "-o", OUT])
 os.environ["RRT_LIB"] = OUT
 sys.path.insert(0, PKG)
 sys.path.insert(0, REPO)
