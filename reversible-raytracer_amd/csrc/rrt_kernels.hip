@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
 // atomics): a tile costs 1x..3x depending on its candidates and coverage, and a
 // static deal per WAVE left most SIMDs idle behind the unluckiest wave
 // (profiles/: 2.6 of 4 resident waves busy on average).
+constexpr int EARLY = 32;              // "none" slots per segment that its owner workgroup zero-fills in the prologue
 constexpr int Q_CAP = 1024;            // entries staged per batch and workgroup (= its threads)
 struct WgQueue {
   unsigned long long ent[Q_CAP];
@@ -441,6 +442,7 @@ struct WgQueue {
 struct WgZeroQueue {
   unsigned long long ent[Q_CAP];
   unsigned ex[Q_CAP];
+  unsigned long long early[(Q_CAP / SEG) * EARLY];   // the head of the workgroup's own segments (see zero_early_load)
   unsigned cursor;
 };
 
@@ -506,15 +508,18 @@ struct QueueState {
   unsigned cnt_e = 0;                // "none" entries staged in the current batch
 };
 
-template <bool WITH_EMPTY>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `mid` runs between the scans and the entry gather (k_fwd issues its first zero-fill stores there).
+template <bool WITH_EMPTY, class Hook>
 __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const unsigned long long* heavy,
                                                const unsigned long long* empty, uint2 cw, unsigned bin0, unsigned nb,
-                                               QueueState& st, int lane, int wave) {
+                                               QueueState& st, int lane, int wave, Hook mid) {
   constexpr int N = WITH_EMPTY ? 4 : 3;
   const unsigned t = threadIdx.x, n = gridDim.x;
   unsigned c[N], ex[N], tot[N];
   c[0] = cw.x & 0xffffu; c[1] = cw.x >> 16; c[2] = cw.y & 0xffffu;
-  if (WITH_EMPTY) c[N - 1] = cw.y >> 16;
+  if (WITH_EMPTY) c[N - 1] = (cw.y >> 16) > EARLY ? (cw.y >> 16) - EARLY : 0u;   // the owner takes the first EARLY
   block_excl_scan<WAVES, N>(c, q.scan, lane, wave, ex, tot);
   q.ex[0][t] = ex[0]; q.ex[1][t] = ex[1]; q.ex[2][t] = ex[2];
   q.cnt01[t] = cw.x;
@@ -522,6 +527,7 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
   if (t == 0) { q.cursor = 0; if (WITH_EMPTY) z->cursor = 0; }
   __syncthreads();
   { const int gw = blockIdx.x * WAVES + wave; (void)gw; RRT_STAMP_FWD(6, ~0ull); }
+  mid();
   const unsigned end = st.base + tot[0] + tot[1] + tot[2];
   const unsigned end_e = WITH_EMPTY ? st.base_e + tot[N - 1] : 0u;
   const unsigned g = st.next + t * n, ge = st.next_e + t * n;
@@ -549,7 +555,7 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
       const unsigned start = cls == 0 ? 0u : (cls == 1 ? (c01 & 0xffffu) : (c01 & 0xffffu) + (c01 >> 16));
       q.ent[t] = heavy[(size_t)(bin0 + lo) * SEG + start + (x - pre[lo])];
     }
-    if (on_e) z->ent[t] = empty[(size_t)(bin0 + le) * SEG + (xe - z->ex[le])];
+    if (on_e) z->ent[t] = empty[(size_t)(bin0 + le) * SEG + EARLY + (xe - z->ex[le])];
   }
   const unsigned cnt = st.next < end ? (end - st.next + n - 1) / n : 0u;
   st.next += cnt * n;
@@ -561,6 +567,22 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
   }
   __syncthreads();
   return cnt;
+}
+
+// k_fwd: HBM should not idle while the workgroups sort out their lists, so every segment
+// sets its first EARLY "none" entries aside for its OWNER (segment bin0 + j belongs to
+// workgroup j mod gridDim.x): no scan, no search, a contiguous read that is in flight from
+// the first instruction of the kernel, and the zero-fill stores leave ~1.5 us into it.  Only
+// the rest of a segment's "none" entries is dealt through the balanced queue (a workgroup
+// left to zero-fill ALL its own segments ran 5 us behind the others).
+__device__ __forceinline__ unsigned long long zero_early_load(const KArgs& a, unsigned bin0, unsigned nb) {
+  const unsigned n = gridDim.x, t = threadIdx.x;
+  if (t >= (Q_CAP / SEG) * EARLY) return ~0ull;
+  const unsigned j = (blockIdx.x + n - bin0 % n) % n + (t / EARLY) * n;   // chunk-relative own segment
+  if (j >= nb) return ~0ull;
+  const unsigned size = a.blk_counts[2 * (bin0 + j) + 1] >> 16;
+  const unsigned long long e = a.empty[(size_t)(bin0 + j) * SEG + t % EARLY];
+  return t % EARLY < size ? e : ~0ull;
 }
 
 // One wave: next entry of the batch, or false when it is exhausted.
@@ -603,6 +625,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
   // (the segment sizes are in flight under the staging)
   uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
                                                            : make_uint2(0u, 0u);
+  unsigned long long early = zero_early_load(a, 0u, min(chunk, (unsigned)a.n_bins));
   stage_scene(a, s_scene);
   RRT_STAMP_FWD(5, ~0ull);
 
@@ -639,8 +662,15 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
     if (bin0) {
       __syncthreads();                     // previous batch fully consumed
       cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
+      early = zero_early_load(a, bin0, nb);
     }
-    const unsigned cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave);
+    if (threadIdx.x < (Q_CAP / SEG) * EARLY) s_z.early[threadIdx.x] = early;
+    const unsigned cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave, [&] {
+      for (unsigned i = wave; i < (Q_CAP / SEG) * EARLY; i += WAVES) {
+        const unsigned long long e = lane_bcast64(s_z.early[i], 0);
+        if (e != ~0ull) zero_tile(e);
+      }
+    });
     const unsigned cnt_e = qs.cnt_e;
     const unsigned per = cnt ? (cnt_e + cnt - 1) / cnt : 0;
     RRT_STAMP_FWD(1, ~0ull);
@@ -851,7 +881,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
       __syncthreads();                     // previous batch fully consumed
       cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
     }
-    const unsigned cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave);
+    const unsigned cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave, NoHook());
     unsigned long long e_cur = 0, e_nxt = 0;
     bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
     F3 g[P];
