@@ -59,6 +59,8 @@ typedef const __attribute__((address_space(4))) float* cfptr;
 typedef const __attribute__((address_space(4))) unsigned long long* cuptr;
 __device__ __forceinline__ cfptr as_const(const float* p) { return (cfptr)p; }
 __device__ __forceinline__ cuptr as_const(const unsigned long long* p) { return (cuptr)p; }
+typedef const __attribute__((address_space(4))) unsigned* cu32ptr;
+__device__ __forceinline__ cu32ptr as_const_u32(const unsigned* p) { return (cu32ptr)p; }
 
 struct F3 {
   float x, y, z;
@@ -112,6 +114,9 @@ struct KArgs {
   const unsigned* blk_counts;     // [n_bins][2] per prep-block: #tiles with 3+ candidates | 2 candidates << 16,
                                   //             1 candidate | none << 16
   int n_bins;                     // prep workgroups = list segments of SEG slots
+  unsigned long long* wgq;        // [batches * workgroups][Q_CAP] the queue batches the last render kernel dealt itself,
+  unsigned* wgq_cnt;              // [batches * workgroups]        kept so that a backward on the same setup reads its
+  int use_saved;                  // share back (1) instead of redoing scans, searches and the entry gather
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
@@ -514,7 +519,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <bool WITH_EMPTY, class Hook>
 __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const unsigned long long* heavy,
                                                const unsigned long long* empty, uint2 cw, unsigned bin0, unsigned nb,
-                                               QueueState& st, int lane, int wave, Hook mid) {
+                                               QueueState& st, int lane, int wave, Hook mid,
+                                               unsigned long long* save, unsigned* save_cnt) {
   constexpr int N = WITH_EMPTY ? 4 : 3;
   const unsigned t = threadIdx.x, n = gridDim.x;
   unsigned c[N], ex[N], tot[N];
@@ -553,11 +559,14 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
     if (on) {
       const unsigned c01 = q.cnt01[lo];
       const unsigned start = cls == 0 ? 0u : (cls == 1 ? (c01 & 0xffffu) : (c01 & 0xffffu) + (c01 >> 16));
-      q.ent[t] = heavy[(size_t)(bin0 + lo) * SEG + start + (x - pre[lo])];
+      const unsigned long long e = heavy[(size_t)(bin0 + lo) * SEG + start + (x - pre[lo])];
+      q.ent[t] = e;
+      save[t] = e;
     }
     if (on_e) z->ent[t] = empty[(size_t)(bin0 + le) * SEG + EARLY + (xe - z->ex[le])];
   }
   const unsigned cnt = st.next < end ? (end - st.next + n - 1) / n : 0u;
+  if (t == 0) *save_cnt = cnt;
   st.next += cnt * n;
   st.base = end;
   if (WITH_EMPTY) {
@@ -665,12 +674,13 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
       early = zero_early_load(a, bin0, nb);
     }
     if (threadIdx.x < (Q_CAP / SEG) * EARLY) s_z.early[threadIdx.x] = early;
+    const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
     const unsigned cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave, [&] {
       for (unsigned i = wave; i < (Q_CAP / SEG) * EARLY; i += WAVES) {
         const unsigned long long e = lane_bcast64(s_z.early[i], 0);
         if (e != ~0ull) zero_tile(e);
       }
-    });
+    }, a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
     const unsigned cnt_e = qs.cnt_e;
     const unsigned per = cnt ? (cnt_e + cnt - 1) / cnt : 0;
     RRT_STAMP_FWD(1, ~0ull);
@@ -858,8 +868,16 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // chunk of list segments per batch: one per thread, and no more than Q_CAP entries for this workgroup
   const unsigned chunk = min((unsigned)BLOCK, max(1u, Q_CAP * gridDim.x / SEG));
-  uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
-                                                           : make_uint2(0u, 0u);
+  // (in flight under the staging: the saved queue batch, or the segment sizes to deal one)
+  uint2 cw = make_uint2(0u, 0u);
+  unsigned saved_cnt = 0;
+  unsigned long long saved_ent = 0;
+  if (a.use_saved) {
+    saved_cnt = as_const_u32(a.wgq_cnt)[blockIdx.x];
+    saved_ent = threadIdx.x < saved_cnt ? a.wgq[(size_t)blockIdx.x * Q_CAP + threadIdx.x] : 0ull;
+  } else if (threadIdx.x < min(chunk, (unsigned)a.n_bins)) {
+    cw = reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x];
+  }
   if (a.lds_scene)
     for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
   stage_scene(a, s_scene);          // ends with the workgroup barrier
@@ -877,11 +895,27 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   qs.next = blockIdx.x;
   for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
     const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
+    const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
     if (bin0) {
       __syncthreads();                     // previous batch fully consumed
-      cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
+      if (a.use_saved) {
+        saved_cnt = as_const_u32(a.wgq_cnt)[slot];
+        saved_ent = threadIdx.x < saved_cnt ? a.wgq[slot * Q_CAP + threadIdx.x] : 0ull;
+      } else {
+        cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
+      }
     }
-    const unsigned cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave, NoHook());
+    unsigned cnt;
+    if (a.use_saved) {
+      // the forward pass on this setup dealt exactly this share: one contiguous read
+      cnt = saved_cnt;
+      if (threadIdx.x < cnt) s_q.ent[threadIdx.x] = saved_ent;
+      if (threadIdx.x == 0) s_q.cursor = 0;
+      __syncthreads();
+    } else {
+      cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave, NoHook(),
+                              a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
+    }
     unsigned long long e_cur = 0, e_nxt = 0;
     bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
     F3 g[P];
@@ -1108,7 +1142,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Geometry {
   int P, ncols, nwords, tiles_x, tiles_y;
   long long n_tiles, n_bins;
-  size_t ps_off, hdr_off, acc_off, counts_off, mask_off, heavy_off, empty_off, total;
+  size_t ps_off, hdr_off, acc_off, counts_off, mask_off, heavy_off, empty_off, wgq_off, wgq_cnt_off, total;
+  unsigned blocks_fwd, blocks_bwd;   // persistent grids of the render kernels
 };
 
 // Rows per wave tile.  P = 4 (64x4-pixel tiles) once the launch has enough
@@ -1122,6 +1157,33 @@ int tuned_P() {
     cached = (p == 1 || p == 2 || p == 4) ? p : 0;
   }
   return cached;
+}
+
+// Persistent launches: enough workgroups to fill every CU at the kernels'
+// register-limited occupancy, never more than there are tiles.
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
+  long long want = (long long)device_cus() * wgs_per_cu;
+  long long need = (n_tiles + WAVES - 1) / WAVES;
+  if (need < 1) need = 1;
+  return (unsigned)(want < need ? want : need);
+}
+
+int tuned_wgs(const char* name, int dflt) {
+  const char* e = getenv(name);
+  int x = e ? atoi(e) : 0;
+  return x > 0 ? x : dflt;
 }
 
 Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
@@ -1143,7 +1205,17 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.mask_off = align_up(g.counts_off + (size_t)g.n_bins * 2 * sizeof(unsigned), 16);
   g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
   g.empty_off = g.heavy_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long);
-  g.total = align_up(g.empty_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long), 16);
+  // saved queue batches: one Q_CAP-entry slot per (batch of list segments, workgroup)
+  g.blocks_fwd = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_FWD_WGS", 1));
+  g.blocks_bwd = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 1));
+  const unsigned blocks = g.blocks_fwd > g.blocks_bwd ? g.blocks_fwd : g.blocks_bwd;
+  const unsigned fewest = g.blocks_fwd < g.blocks_bwd ? g.blocks_fwd : g.blocks_bwd;
+  long long chunk = (long long)Q_CAP * fewest / SEG;
+  chunk = chunk < 1 ? 1 : (chunk > BLOCK ? BLOCK : chunk);
+  const size_t slots = (size_t)((g.n_bins + chunk - 1) / chunk) * blocks;
+  g.wgq_off = align_up(g.empty_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long), 16);
+  g.wgq_cnt_off = g.wgq_off + slots * Q_CAP * sizeof(unsigned long long);
+  g.total = align_up(g.wgq_cnt_off + slots * sizeof(unsigned), 16);
   return g;
 }
 
@@ -1201,6 +1273,9 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.lds_scene = ((long long)s->B * s->S <= LDS_RECS && !getenv("RRT_TUNE_NOLDS")) ? 1 : 0;
   a.blk_counts = (const unsigned*)(base + g.counts_off);
   a.n_bins = (int)g.n_bins;
+  a.wgq = (unsigned long long*)(base + g.wgq_off);
+  a.wgq_cnt = (unsigned*)(base + g.wgq_cnt_off);
+  a.use_saved = 0;
   a.n_waves = 0;
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
   a.image = nullptr;
@@ -1227,27 +1302,6 @@ int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStr
   return RRT_OK;
 }
 
-// Persistent launches: enough workgroups to fill every CU at the kernels'
-// register-limited occupancy, never more than there are tiles.
-int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
-
-unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
-  long long want = (long long)device_cus() * wgs_per_cu;
-  long long need = (n_tiles + WAVES - 1) / WAVES;
-  if (need < 1) need = 1;
-  return (unsigned)(want < need ? want : need);
-}
-
 template <int P>
 void launch_fwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
   if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
@@ -1260,12 +1314,6 @@ void launch_bwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream
   if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
   else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
   else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
-}
-
-int tuned_wgs(const char* name, int dflt) {
-  const char* e = getenv(name);
-  int x = e ? atoi(e) : 0;
-  return x > 0 ? x : dflt;
 }
 
 }  // namespace
@@ -1326,7 +1374,7 @@ int rrt_render_fwd(const rrt_scene* s, const rrt_view* v, float* image_out, void
     if (rc != RRT_OK) return rc;
   }
   if (g.n_tiles == 0) return RRT_OK;
-  unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_FWD_WGS", 1));
+  unsigned blocks = g.blocks_fwd;
   a.n_waves = (int)blocks * WAVES;
   if (g.P == 4) launch_fwd<4>(a, blocks, a.v.shader, a.v.specular, st);
   else if (g.P == 2) launch_fwd<2>(a, blocks, a.v.shader, a.v.specular, st);
@@ -1361,8 +1409,10 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
     return e == hipSuccess ? RRT_OK : hip_fail(e);
   }
   if (s->S > 0) {
-    unsigned blocks = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 1));
+    unsigned blocks = g.blocks_bwd;
     a.n_waves = (int)blocks * WAVES;
+    // the kernel that ran on this setup before (forward or backward) left its queue batches behind
+    a.use_saved = ((v->flags & RRT_FLAG_REUSE_SETUP) && g.blocks_fwd == g.blocks_bwd && !getenv("RRT_TUNE_NOSAVED")) ? 1 : 0;
     if (g.P == 4) launch_bwd<4>(a, blocks, a.v.shader, a.v.specular, st);
     else if (g.P == 2) launch_bwd<2>(a, blocks, a.v.shader, a.v.specular, st);
     else launch_bwd<1>(a, blocks, a.v.shader, a.v.specular, st);
