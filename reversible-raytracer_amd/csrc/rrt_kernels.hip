@@ -117,6 +117,8 @@ struct KArgs {
   unsigned long long* wgq;        // [batches * workgroups][Q_CAP] the queue batches the last render kernel dealt itself,
   unsigned* wgq_cnt;              // [batches * workgroups]        kept so that a backward on the same setup reads its
   int use_saved;                  // share back (1) instead of redoing scans, searches and the entry gather
+  int chunk;                      // list segments per queue batch: at most one per thread, and few enough that a
+                                  // workgroup's share of their tiles fits its queues (Q_CAP)
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
   const int gw = global_wave<WAVES>(lane);
   const int wave = gw - (int)blockIdx.x * WAVES;
   // chunk of list segments per batch: one per thread, and no more than Q_CAP tiles for this workgroup
-  const unsigned chunk = min((unsigned)BLOCK, max(1u, Q_CAP * gridDim.x / SEG));
+  const unsigned chunk = (unsigned)a.chunk;
   RRT_STAMP_FWD(0, ~0ull);
   // (the segment sizes are in flight under the staging)
   uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   global_wave<WAVES>(lane);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // chunk of list segments per batch: one per thread, and no more than Q_CAP entries for this workgroup
-  const unsigned chunk = min((unsigned)BLOCK, max(1u, Q_CAP * gridDim.x / SEG));
+  const unsigned chunk = (unsigned)a.chunk;
   // (in flight under the staging: the saved queue batch, or the segment sizes to deal one)
   uint2 cw = make_uint2(0u, 0u);
   unsigned saved_cnt = 0;
@@ -1144,6 +1146,7 @@ struct Geometry {
   long long n_tiles, n_bins;
   size_t ps_off, hdr_off, acc_off, counts_off, mask_off, heavy_off, empty_off, wgq_off, wgq_cnt_off, total;
   unsigned blocks_fwd, blocks_bwd;   // persistent grids of the render kernels
+  int chunk;                         // list segments per queue batch
 };
 
 // Rows per wave tile.  P = 4 (64x4-pixel tiles) once the launch has enough
@@ -1212,6 +1215,9 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   const unsigned fewest = g.blocks_fwd < g.blocks_bwd ? g.blocks_fwd : g.blocks_bwd;
   long long chunk = (long long)Q_CAP * fewest / SEG;
   chunk = chunk < 1 ? 1 : (chunk > BLOCK ? BLOCK : chunk);
+  const int forced = tuned_wgs("RRT_TUNE_CHUNK", 0);           // tests: several batches at small sizes
+  if (forced > 0 && forced < chunk) chunk = forced;
+  g.chunk = (int)chunk;
   const size_t slots = (size_t)((g.n_bins + chunk - 1) / chunk) * blocks;
   g.wgq_off = align_up(g.empty_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long), 16);
   g.wgq_cnt_off = g.wgq_off + slots * Q_CAP * sizeof(unsigned long long);
@@ -1276,6 +1282,7 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.wgq = (unsigned long long*)(base + g.wgq_off);
   a.wgq_cnt = (unsigned*)(base + g.wgq_cnt_off);
   a.use_saved = 0;
+  a.chunk = g.chunk;
   a.n_waves = 0;
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
   a.image = nullptr;

@@ -479,3 +479,38 @@ def test_max_shapes_cull_vs_brute_force(dev):
     for k in (1, 2, 3):
         assert np.abs(a[k] - b[k]).max() <= 1e-4 * max(np.abs(b[k]).max(), 1e-20)
     assert (a[0].max(-1) > 0).mean() > 0.05
+
+
+@pytest.mark.parametrize("chunk", [1, 3])
+def test_several_queue_batches(dev, chunk, monkeypatch):
+    """the render kernels walk the list segments in batches (one batch at bench
+    sizes); RRT_TUNE_CHUNK forces several at a test size.  Image bit-identical
+    to the one-batch run, gradients equal up to float-atomic order."""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(12, seed=3)
+    G = np.random.RandomState(1).randn(640, 1024, 3)
+    kw = dict(x_dims=640, y_dims=1024, antialias_samples=1)      # 16 x 3 list segments at P = 4
+    ref = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    monkeypatch.setenv("RRT_TUNE_CHUNK", str(chunk))
+    got = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    assert np.array_equal(got[0], ref[0])
+    for a, b, what in zip(got[1:], ref[1:], ("g_w2o", "g_material", "g_light")):
+        assert_grad_close(a, b, what, rtol=1e-4)
+    oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **kw)
+    assert_image_close(got[0], oi, "image")
+    assert_grad_close(got[1], ow, "g_w2o")
+
+
+def test_backward_with_and_without_saved_queues(dev, monkeypatch):
+    """a backward on the forward's setup reads the queue batches the forward
+    dealt; RRT_TUNE_NOSAVED makes it deal them again -- same gradients"""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(20, seed=5)
+    G = np.random.RandomState(2).randn(512, 512, 3)
+    kw = dict(x_dims=512, y_dims=512, antialias_samples=2, jitter=11)
+    a = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    monkeypatch.setenv("RRT_TUNE_NOSAVED", "1")
+    b = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    assert np.array_equal(a[0], b[0])
+    for x, y, what in zip(a[1:], b[1:], ("g_w2o", "g_material", "g_light")):
+        assert_grad_close(x, y, what, rtol=1e-4)
