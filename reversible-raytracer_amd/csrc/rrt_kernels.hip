@@ -85,6 +85,10 @@ __device__ unsigned long long* g_stamps = nullptr;   // [n_tiles][8]
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
     if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
   } while (0)
+#define RRT_STAMP_VAL(slot, value)                                                          \
+  do {                                                                                      \
+    if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = (unsigned long long)(value);   \
+  } while (0)
 // k_fwd: per-wave real-time stamps / counters in row `gw` (tools/stamp_fwd.py)
 #define RRT_STAMP_FWD(slot, value_or_rt)                                                    \
   do {                                                                                      \
@@ -95,6 +99,7 @@ __device__ unsigned long long* g_stamps = nullptr;   // [n_tiles][8]
 #else
 #define RRT_STAMP(slot) do {} while (0)
 #define RRT_STAMP_RT(slot) do {} while (0)
+#define RRT_STAMP_VAL(slot, value) do {} while (0)
 #define RRT_STAMP_FWD(slot, value_or_rt) do {} while (0)
 #endif
 
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             held = true; held_k = k; held_b = t.b; held_val = mine_val;
           }
-          RRT_STAMP(5);
+          RRT_STAMP_VAL(5, blockIdx.x);
         }
       }
       RRT_STAMP(6);
@@ -1077,14 +1082,61 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
 }
 
 // --------------------------------------------------------------- finalize --
-// One block; loops are tiny (B*S rows of 32 floats).  Leaves the accumulator
+// One block; the work is tiny (B*S rows of 32 floats) and the kernel is pure latency, so
+// the common case -- every scene has its own transforms and materials, or there is one scene
+// -- reads each accumulator row ONCE (float4 loads, all in flight together), derives all three
+// gradients from it, re-zeroes it, and sums the light terms with DPP wave sums and one
+// barrier.  Shared (stride-0) parameters take the general path below.  Leaves the accumulator
 // rows zeroed for the next backward.
 __global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, const float* hdr, const float* mat,
                                                   long long mat_bs, const float* light, long long w2o_bs,
                                                   float* g_w2o, float* g_mat, float* g_light) {
   __shared__ float s_red[256][6];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Bw = w2o_bs ? B : 1, Bm = mat_bs ? B : 1;
+  if (B == 1 || (w2o_bs && mat_bs)) {
+    float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < B * S; idx += blockDim.x) {
+      const int b = idx / S, k = idx - b * S;
+      float row[ACC_STRIDE];
+      float4* src = reinterpret_cast<float4*>(acc + (size_t)idx * ACC_STRIDE);
+#pragma unroll
+      for (int q = 0; q < ACC_STRIDE / 4; ++q) {
+        const float4 x = src[q];
+        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+      }
+#pragma unroll
+      for (int q = 0; q < ACC_STRIDE / 4; ++q) src[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g_w2o) {
+        float gw[12];
+        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+        finalize_w2o<float>(row, hdr + (size_t)b * HDR_STRIDE, gw);
+        for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
+      }
+      if (g_mat) {
+        float gm[7];
+        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+        finalize_material<float>(row, light, gm);
+        for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
+      }
+      if (g_light) finalize_light_accum<float>(row, mat + b * mat_bs + 7 * k, gl);
+    }
+    if (g_light) {
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const float tot = wave_sum_to_lane63(gl[n]);
+        if (lane == 63) s_red[wave][n] = tot;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float g[6];
+        for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
+        finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
+        for (int n = 0; n < 6; ++n) g_light[n] = g[n];
+      }
+    }
+    return;
+  }
   if (g_w2o) {
     for (int idx = tid; idx < Bw * S; idx += blockDim.x) {
       int bw = idx / S, k = idx - bw * S;
@@ -1112,16 +1164,15 @@ __global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, cons
       int b = idx / S, k = idx - b * S;
       finalize_light_accum<float>(acc + (size_t)idx * ACC_STRIDE, mat + b * mat_bs + 7 * k, gl);
     }
-    for (int n = 0; n < 6; ++n) s_red[tid][n] = gl[n];
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-      if (tid < stride)
-        for (int n = 0; n < 6; ++n) s_red[tid][n] += s_red[tid + stride][n];
-      __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const float tot = wave_sum_to_lane63(gl[n]);
+      if (lane == 63) s_red[wave][n] = tot;
     }
+    __syncthreads();
     if (tid == 0) {
       float g[6];
-      for (int n = 0; n < 6; ++n) g[n] = s_red[0][n];
+      for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
       finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
       for (int n = 0; n < 6; ++n) g_light[n] = g[n];
     }

@@ -50,16 +50,18 @@ for _ in range(3):
 torch.cuda.synchronize()
 n_tiles = (args.size // 64) * (args.size // 4)
 stamps = torch.zeros((n_tiles + 64, 8), dtype=torch.int64, device=dev)
-rc = job.L.rrt_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+job.fwd()
+torch.cuda.synchronize()
+rc = job.L.rrt_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))     # after the forward: k_fwd stamps the same buffer
 assert rc == 0, rc
-job.fwd(); job.bwd()
+job.bwd()
 torch.cuda.synchronize()
 st = stamps.cpu().numpy()[:n_tiles]
 heavy = st[:, 6] != 0
 h = st[heavy].astype(np.float64)
 print("tiles", n_tiles, "non-empty", heavy.sum())
-names = ["0->1 grad wait + LDS stage + prefetch issue", "1->2 phase 1 (winners; multi-candidate tiles)",
-         "2->3 load_shape", "3->4 adjoint rows", "4->5 DPP reduce + atomic", "5->6 loop exit"]
+names = ["0->1 grad wait + LDS stage + prefetch issue", "(slot 2 holds the end-of-tile real time)",
+         "(slot 2 holds the end-of-tile real time)", "3->4 adjoint rows"]
 tot = h[:, 6] - h[:, 0]
 print("total cycles/wave: median %.0f mean %.0f p90 %.0f" % (np.median(tot), tot.mean(), np.percentile(tot, 90)))
 for i, nm in enumerate(names):
@@ -93,3 +95,16 @@ print("busy waves per SIMD over %d slices of the span: %s" % (nb, " ".join("%.1f
 dur = (h[:, 2] - h[:, 7])[ok] / 100.0
 print("tile duration (us): median %.2f p10 %.2f p90 %.2f p99 %.2f max %.2f" % (
     np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
+# per-workgroup finish times (slot 5 = workgroup id of the tile's last adjoint pass)
+ok = ok & (h[:, 5] < 65536)
+wg = h[ok, 5].astype(np.int64)
+dur = (h[:, 2] - h[:, 7])[ok] / 100.0
+endt = (h[ok, 2] - t_first) / 100.0
+last = np.zeros(wg.max() + 1)
+np.maximum.at(last, wg, endt)
+cntw = np.bincount(wg, minlength=len(last))
+busy = np.zeros(len(last)); np.add.at(busy, wg, dur)
+print("workgroup finish (us): min %.1f p10 %.1f median %.1f p90 %.1f max %.1f; tiles per workgroup %d..%d; "
+      "sum of tile times per workgroup (us): min %.0f median %.0f max %.0f" % (
+          last.min(), np.percentile(last, 10), np.median(last), np.percentile(last, 90), last.max(), cntw.min(), cntw.max(),
+          busy.min(), np.median(busy), busy.max()))
