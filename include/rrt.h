@@ -65,11 +65,12 @@ typedef enum rrt_status {
 
 /* rrt_view.flags */
 #define RRT_FLAG_NO_CULL 1u      /* brute force: test every shape at every ray */
-#define RRT_FLAG_REUSE_SETUP 2u  /* the packed scene left in `workspace` by an
-                                    earlier render call with the SAME scene and
-                                    camera is still valid: skip re-packing
-                                    (backward right after its forward; repeated
-                                    forwards of an unchanged scene) */
+#define RRT_FLAG_REUSE_SETUP 2u  /* the packed scene, tile lists and work-queue
+                                    batches left in `workspace` by an earlier
+                                    render call with the SAME scene, camera and
+                                    view are still valid: skip re-packing and
+                                    re-dealing (backward right after its forward;
+                                    repeated forwards of an unchanged scene) */
 
 #define RRT_FLAG_SKIP_FINALIZE 4u /* rrt_render_bwd, measurement only: run the adjoint kernel but not the
                                     final chain to w2o/material/light (g_* are left untouched and the
@@ -123,9 +124,11 @@ const char* rrt_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */
 int rrt_last_hip_error(void);
 
-/* Bytes of device scratch either render call needs (16-byte aligned base).
- * Holds the packed per-(scene,shape) parameters, per-scene headers and the
- * float32 gradient accumulators.  Returns 0 on invalid arguments. */
+/* Bytes of device scratch either render call needs (16-byte aligned base, no
+ * initialisation required).  Holds the packed per-(scene,shape) parameters,
+ * per-scene headers, the float32 gradient accumulators, the per-tile candidate
+ * masks and tile lists, and the work-queue batches of the last render kernel
+ * (about 24 B per 64xP-pixel tile).  Returns 0 on invalid arguments. */
 size_t rrt_workspace_bytes(const rrt_scene* s, const rrt_view* v);
 
 /* Forward: replaces Scene.build() + theano.function([], image)()
