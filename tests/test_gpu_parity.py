@@ -514,3 +514,60 @@ def test_backward_with_and_without_saved_queues(dev, monkeypatch):
     assert np.array_equal(a[0], b[0])
     for x, y, what in zip(a[1:], b[1:], ("g_w2o", "g_material", "g_light")):
         assert_grad_close(x, y, what, rtol=1e-4)
+
+
+def test_gradient_descent_loss_curve_matches_oracle(dev):
+    """the match_mirror.py loop (match_mirror.py:36-53) with GDOptimizer's update
+    rule (optimize.py:19-27), free-running on the GPU for 25 steps.  At every step the float64
+    oracle, evaluated at the GPU's current parameters, must give the same loss and image, and
+    the same gradient up to the float32 noise floor of these formulas -- measured, at the same
+    point, by the oracle itself run in float32 (a grazing ray makes dLoss/dcentre jump by
+    O(|g|) for a 1e-7 change of the centre; the free-running float64 trajectory therefore
+    separates from any float32 one at the first such event, here around step 21)."""
+    import rrt
+    from rrt import synthetic
+    w2o0, mat, light, kinds = synthetic.match_mirror(with_square=True)
+    n, lr, mom = 96, 8e-6, 0.1
+    kw = dict(x_dims=n, y_dims=n, antialias_samples=1, jitter="center")
+    okw = dict(x_dims=n, y_dims=n, antialias_samples=1)
+
+    def w2o_of(centres):
+        # Sphere(translate(c)): w2o = translate(c)^-1 -> last column -c (transform.py:60-70)
+        w = torch.tensor(w2o0, dtype=centres.dtype, device=centres.device)
+        col = torch.cat([-centres, w[2:, :, 3]], 0)              # the Square keeps its own transform
+        return torch.cat([w[:, :, :3], col[:, :, None]], 2)
+
+    def oracle_at(c32, target, dtype):
+        co = c32.to(dtype).requires_grad_(True)
+        img = O.render(w2o_of(co), torch.tensor(mat, dtype=dtype), torch.tensor(light, dtype=dtype), list(kinds),
+                       dtype=dtype, **okw)
+        loss = ((img - target.to(dtype)) ** 2).sum()
+        (g,) = torch.autograd.grad(loss, co)
+        return img.detach().double(), loss.item(), g.double()
+
+    c = torch.tensor([[-.5, -.5, 4.], [.5, .5, 4.]], device=dev, requires_grad=True)
+    tm, tl = torch.tensor(mat, device=dev), torch.tensor(light, device=dev)
+    target = torch.flip(rrt.render(w2o_of(c.detach()), tm, tl, kinds, **kw), dims=[1])     # np.fliplr
+    target_cpu = target.cpu()
+    vel = torch.zeros_like(c)
+    losses, worst = [], 0.0
+    for _ in range(25):
+        img = rrt.render(w2o_of(c), tm, tl, kinds, **kw)
+        loss = ((img - target) ** 2).sum()
+        (g,) = torch.autograd.grad(loss, c)
+        c_cpu = c.detach().cpu()
+        img64, loss64, g64 = oracle_at(c_cpu, target_cpu, torch.float64)
+        _, _, g32 = oracle_at(c_cpu, target_cpu, torch.float32)
+        assert_image_close(img.detach().cpu().double().numpy(), img64.numpy(), "image")
+        assert abs(loss.item() - loss64) <= 1e-5 * loss64
+        scale = g64.abs().max().item()
+        err = (g.cpu().double() - g64).abs().max().item()
+        floor = (g32 - g64).abs().max().item()
+        assert err <= max(GRAD_RTOL * scale, 4.0 * floor), (err, scale, floor)
+        worst = max(worst, err / scale)
+        losses.append(loss.item())
+        with torch.no_grad():
+            vel = mom * vel - lr * g
+            c += vel
+    assert losses[-1] < 0.93 * losses[0]
+    assert (c.detach().cpu() - torch.tensor([[-.5, -.5, 4.], [.5, .5, 4.]])).abs().max() > 0.05
