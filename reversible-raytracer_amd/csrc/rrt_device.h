@@ -233,11 +233,12 @@ RRT_HD bool hit_square(const T r[3], const T o[3], T& t) {
 // --------------------------------------------------------------- shading --
 // x ** y with C pow() semantics for the cases a render can produce
 // (shader.py:45): negative base is finite for integer-valued y, NaN otherwise.
-// Returns |x|^y with sign; also |x|^(y-1) with sign through pw1 (for the adjoint).
+// Returns |x|^y with sign; also |x|^(y-1) with sign through pw1 and log2|x| through l2
+// (both for the adjoint).
 template <class T>
-RRT_HD T pow_signed(T x, T y, int flags, T& pw1) {
+RRT_HD T pow_signed(T x, T y, int flags, T& pw1, T& l2) {
   T a = m_abs<T>(x);
-  T l2 = m_log2<T>(a);
+  l2 = m_log2<T>(a);
   T p = (y == T(0)) ? T(1) : m_exp2<T>(y * l2);
   T p1 = (y == T(1)) ? T(1) : m_exp2<T>((y - T(1)) * l2);
   if (x < T(0)) {
@@ -270,8 +271,8 @@ RRT_HD void shade_phong(const T nu[3], const T colI[3], T ks, T kd, T ka, T sh, 
   if (specular) {
     T two = T(2) * dd;
     T s = (two * n0 + L[0]) * look[0] + (two * n1 + L[1]) * look[1] + (two * n2 + L[2]) * look[2];
-    T pw1;
-    phi += ks * pow_signed<T>(s, sh, powf, pw1);
+    T pw1, l2;
+    phi += ks * pow_signed<T>(s, sh, powf, pw1, l2);
   }
   for (int q = 0; q < 3; ++q) {
     T x = phi * colI[q];
@@ -321,11 +322,11 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
     T n[3] = {nu[0] * inv, nu[1] * inv, nu[2] * inv};
     T dd = -(n[0] * L[0] + n[1] * L[1] + n[2] * L[2]);
     T phi = ka + kd * dd;
-    T s = T(0), pw = T(0), pw1 = T(0);
+    T s = T(0), pw = T(0), pw1 = T(0), l2s = T(0);
     if (specular) {
       T two = T(2) * dd;
       s = (two * n[0] + L[0]) * look[0] + (two * n[1] + L[1]) * look[1] + (two * n[2] + L[2]) * look[2];
-      pw = pow_signed<T>(s, sh, powf, pw1);
+      pw = pow_signed<T>(s, sh, powf, pw1, l2s);
       phi += ks * pw;
     }
     // clip(phi*colI, 0, 1): gradient passes where 0 <= x <= 1 (inclusive, as
@@ -345,7 +346,7 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
     if (specular) {
       acc[ACC_KS] += g_phi * pw;
       // d/dshininess = pw * ln(s); only defined for s > 0 (extension, see rrt.h)
-      if (s > T(0)) acc[ACC_SH] += g_phi * ks * pw * (m_log2<T>(s) * T(0.6931471805599453));
+      if (s > T(0)) acc[ACC_SH] += g_phi * ks * pw * (l2s * T(0.6931471805599453));   // l2s = log2(s) from the pow
       T g_s = g_phi * ks * sh * pw1;
       T g_rm[3] = {g_s * look[0], g_s * look[1], g_s * look[2]};
       // rm = 2 dd n + Lhat
