@@ -193,9 +193,13 @@ RRT_HD void xform_dir(const T* A, const T d[3], T r[3]) {
 template <class T>
 struct SphereHit {
   T alpha, beta, ia, q, op[3], Dp, h, t;
+  T ih;       // 1/h (hit_sphere<T, true> only)
 };
 
-template <class T>
+// WITH_IH (the adjoint): h and 1/h from ONE reciprocal square root (h = x rsqrt(x)) instead of a
+// square root here and a reciprocal later -- transcendental ops issue at a quarter of the FP32
+// rate and each one less is ~1 us of k_bwd.  The forward kernels keep the plain square root.
+template <class T, bool WITH_IH = false>
 RRT_HD bool hit_sphere(const T r[3], const T o[3], SphereHit<T>& sh) {
   sh.alpha = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   sh.beta = r[0] * o[0] + r[1] * o[1] + r[2] * o[2];
@@ -206,7 +210,14 @@ RRT_HD bool hit_sphere(const T r[3], const T o[3], SphereHit<T>& sh) {
   sh.op[2] = o[2] - sh.q * r[2];
   sh.Dp = T(1) - (sh.op[0] * sh.op[0] + sh.op[1] * sh.op[1] + sh.op[2] * sh.op[2]);
   bool hit = sh.Dp > T(0);            // false for NaN, as the reference's mask
-  sh.h = m_sqrt<T>((hit ? sh.Dp : T(1)) * sh.ia);
+  const T x = (hit ? sh.Dp : T(1)) * sh.ia;
+  if (WITH_IH) {
+    sh.ih = m_rsqrt<T>(x);
+    sh.h = x * sh.ih;
+  } else {
+    sh.h = m_sqrt<T>(x);
+    sh.ih = T(0);
+  }
   sh.t = -sh.q - sh.h;
   return hit;
 }
@@ -241,6 +252,25 @@ RRT_HD T pow_signed(T x, T y, int flags, T& pw1, T& l2) {
   l2 = m_log2<T>(a);
   T p = (y == T(0)) ? T(1) : m_exp2<T>(y * l2);
   T p1 = (y == T(1)) ? T(1) : m_exp2<T>((y - T(1)) * l2);
+  if (x < T(0)) {
+    if (flags & POW_INT) {
+      if (flags & POW_ODD) p = -p; else p1 = -p1;
+    } else {
+      p = m_nan<T>();
+      p1 = m_nan<T>();
+    }
+  }
+  pw1 = p1;
+  return p;
+}
+
+// The adjoint's variant: |x|^(y-1) by exp2 and |x|^y = |x|^(y-1) |x| (one exp2 instead of two).
+template <class T>
+RRT_HD T pow_signed_adj(T x, T y, int flags, T& pw1, T& l2) {
+  T a = m_abs<T>(x);
+  l2 = m_log2<T>(a);
+  T p1 = (y == T(1)) ? T(1) : m_exp2<T>((y - T(1)) * l2);
+  T p = (y == T(0)) ? T(1) : (a > T(0) ? p1 * a : T(0));   // (0^y = 0 also where 0^(y-1) = inf)
   if (x < T(0)) {
     if (flags & POW_INT) {
       if (flags & POW_ODD) p = -p; else p1 = -p1;
@@ -303,7 +333,7 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
   T t;
   SphereHit<T> sp;
   bool hit;
-  if (kind == KIND_SPHERE) { hit = hit_sphere<T>(r, o, sp); t = sp.t; }
+  if (kind == KIND_SPHERE) { hit = hit_sphere<T, true>(r, o, sp); t = sp.t; }
   else hit = hit_square<T>(r, o, t);
   if (!hit) return false;                                   // miss => exactly zero
 
@@ -326,7 +356,7 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
     if (specular) {
       T two = T(2) * dd;
       s = (two * n[0] + L[0]) * look[0] + (two * n[1] + L[1]) * look[1] + (two * n[2] + L[2]) * look[2];
-      pw = pow_signed<T>(s, sh, powf, pw1, l2s);
+      pw = pow_signed_adj<T>(s, sh, powf, pw1, l2s);
       phi += ks * pw;
     }
     // clip(phi*colI, 0, 1): gradient passes where 0 <= x <= 1 (inclusive, as
@@ -378,7 +408,7 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
     // collected so that only well conditioned quantities appear
     // (beta o' - gamma r' = beta o_perp + D' r';  o' - (beta/alpha) r' = o_perp):
     T gta = g_t * sp.ia;                              // g_t / alpha
-    T g_D = T(-0.5) * gta * sp.ia * m_rcp<T>(sp.h);   // sqrt(Delta) = alpha h
+    T g_D = T(-0.5) * gta * sp.ia * sp.ih;            // sqrt(Delta) = alpha h
     T two_gD = T(2) * g_D;
     T ca = two_gD * sp.alpha;
     for (int q = 0; q < 3; ++q) {
