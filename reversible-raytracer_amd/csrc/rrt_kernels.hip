@@ -10,32 +10,41 @@
 //               records and zeroes the gradient-accumulator rows), then run a
 //               two-level cone-vs-ball cull -> a candidate bit mask per tile;
 //               packed tile entries go to the workgroup's own segment of a "has
-//               candidates" and a "none" list (no atomics, nothing pre-zeroed).
-//   k_fwd<P>    persistent; one WAVE per tile, one lane per pixel column, P rows
-//               per lane.  A workgroup scan of the segment sizes deals list
-//               entries gw, gw + n_waves, ... to wave gw; the packed scene is staged in LDS once and a
-//               shape's record reaches SGPRs by one ds_read_b32 + v_readlane
-//               (scalar loads through the constant address space when the scene
-//               is too big); rays are generated in registers; winners are
-//               shaded shape by shape; each lane stores its RGB triple with one
-//               global_store_dwordx3 (a wave row is 768 contiguous bytes).
-//               Tiles without candidates are only zero-filled.
-//   k_bwd<P>    persistent, one 1024-thread workgroup per CU with an LDS work
-//               queue (filled the same way); tiles without candidates never touch the upstream
-//               gradient; the next tile's gradient rows are requested before
-//               the current tile's arithmetic.  For every candidate shape that
-//               won somewhere in the wave, the lanes it won run the analytic
-//               adjoint with the shape's parameters in SGPRs and add into 22
-//               per-lane accumulators; these are summed across the wave with
-//               DPP (quad_perm / row_shr / row_bcast), added to workgroup-level
-//               LDS accumulators, and each workgroup adds a touched shape row
-//               to HBM once (global_atomic_add_f32).
+//               candidates" list (ordered by cost class: 3+ candidates, 2, 1) and
+//               of a "none" list (no atomics, nothing pre-zeroed).
+//   k_fwd<P>    persistent, one 1024-thread workgroup per CU; one WAVE per tile,
+//               one lane per pixel column, P rows per lane.  Prologue: a
+//               workgroup scan of the segment sizes (DPP) and a binary search
+//               per entry deal the workgroup an equal share of every cost class
+//               into an LDS work queue, expensive first, and its share of the
+//               "none" tiles into a second one (the head of its OWN segments is
+//               zero-filled while that is going on).  A wave pops a tile to
+//               render and, with it, its part of the zero-fill.  The packed
+//               scene is staged in LDS once and a shape's record reaches SGPRs
+//               by one ds_read_b32 + v_readlane (scalar loads through the
+//               constant address space when the scene is too big); rays are
+//               generated in registers; winners are shaded shape by shape; each
+//               lane stores its RGB triple with one global_store_dwordx3 (a wave
+//               row is 768 contiguous bytes).  The dealt queue batch is kept in
+//               the workspace for the backward.
+//   k_bwd<P>    persistent, one 1024-thread workgroup per CU with the same LDS
+//               work queue (read back from the forward's batch when there was
+//               one); tiles without candidates never touch the upstream
+//               gradient; the next tile's gradient rows are requested before the
+//               current tile's arithmetic.  For every candidate shape that won
+//               somewhere in the wave, the lanes it won run the analytic adjoint
+//               with the shape's parameters in SGPRs and add into 22 per-lane
+//               accumulators; these are summed across the wave by a transposing
+//               butterfly (v_permlane32_swap, v_permlane16_swap, DPP), added to
+//               workgroup-level LDS accumulators, and each workgroup adds a
+//               touched shape row to HBM once (global_atomic_add_f32).
 //   k_finalize  chain the accumulator rows back to w2o / material / light and
 //               re-zero them.
 //
 // No MFMA: the path is per-ray quadratic solves, not a contraction.
-// Environment variables RRT_TUNE_* are tuning knobs for experiments (tile rows,
-// persistent grid sizes, LDS staging on/off); defaults are what was measured best.
+// Environment variables RRT_TUNE_* are tuning knobs for experiments and tests (tile
+// rows, persistent grid sizes, LDS staging on/off, queue batch size, saved queues
+// on/off); defaults are what was measured best.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -47,8 +56,8 @@ namespace {
 using namespace rrt;
 
 constexpr int TILE_W = 64;      // one lane per pixel column: a wave row is 768 contiguous bytes
-constexpr int WAVES = 16;       // waves per k_bwd workgroup: ONE 1024-thread workgroup fills a CU at the
-constexpr int BLOCK = WAVES * 64;   // kernel's 4 waves/SIMD, so its LDS work queue balances the whole CU
+constexpr int WAVES = 16;       // waves per render workgroup: ONE 1024-thread workgroup fills a CU at the
+constexpr int BLOCK = WAVES * 64;   // kernels' 4 waves/SIMD, so its LDS work queue balances the whole CU
 // k_prep: wave tiles per workgroup (= threads) and list slots per segment
 constexpr int BIN_RX = 4, BIN_RY = 64, SEG = BIN_RX * BIN_RY;
 constexpr int MAX_WORDS = RRT_MAX_SHAPES / 64;
