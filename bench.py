@@ -293,6 +293,13 @@ def main():
                     "note": None if dom_fwd else "k_bwd skips the gradient of tiles no shape can hit and is bound by "
                                                  "FP32 VALU issue at this coverage, not by HBM (DESIGN.md section 6)"}
 
+        # the other render kernel, same definition (k_fwd is the HBM-bound one: pure image writes)
+        other = "k_bwd" if dom_fwd else "k_fwd"
+        roofline_other = {"bound": "hbm", "kernel": other, "achieved": kernels[other + "_GBs"], "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": kernels[other + "_GBs"] / HBM_PEAK_GBS}
+    else:
+        roofline_other = None
+
     if rank == 0:
         cpu = None
         parity = None
@@ -313,7 +320,8 @@ def main():
                                     "c5": "config 5: 256 orbit scenes (2 spheres, stereo cameras, no specular), 64x64, "
                                           "antialias_samples=4, one batched launch"}[args.workload],
                        "cull": not args.no_cull, "parallelism": "rowband%d" % world},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "roofline_other_kernel": roofline_other, "kernels": kernels, "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(out))
     if use_dist:
