@@ -571,3 +571,70 @@ def test_gradient_descent_loss_curve_matches_oracle(dev):
             c += vel
     assert losses[-1] < 0.93 * losses[0]
     assert (c.detach().cpu() - torch.tensor([[-.5, -.5, 4.], [.5, .5, 4.]])).abs().max() > 0.05
+
+
+def _random_scene(rs):
+    """shapes with general affine world->object maps (rotation about a random axis, anisotropic
+    scale, translation), a few of them Squares; random materials and light"""
+    S = int(rs.randint(1, 7))
+    w2o, mat, kinds = np.zeros((S, 3, 4)), np.zeros((S, 7)), np.zeros(S, np.uint8)
+    for k in range(S):
+        z = rs.uniform(3.0, 9.0)
+        c = np.array([rs.uniform(-0.35, 0.35) * z, rs.uniform(-0.35, 0.35) * z, z])
+        axis = rs.randn(3); axis /= np.linalg.norm(axis)
+        ang = rs.uniform(0, np.pi)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        kinds[k] = 1 if rs.rand() < 0.25 else 0
+        sc = rs.uniform(0.25, 0.9, size=3) * (z / 5.0) * (2.0 if kinds[k] else 1.0)
+        o2w = R @ np.diag(sc)                                   # object -> world: translate * rotate * scale
+        inv = np.linalg.inv(o2w)
+        w2o[k, :, :3], w2o[k, :, 3] = inv, -inv @ c
+        mat[k] = [*rs.uniform(0.05, 0.95, 3), rs.uniform(0.0, 0.5), rs.uniform(0.4, 0.9), rs.uniform(0.1, 0.5),
+                  float(rs.choice([1.0, 2.0, 7.0, 20.0, 50.0]))]
+    light = np.array([*rs.uniform(-1, 1, 2), rs.uniform(0.5, 2.0), *rs.uniform(0.5, 1.0, 3)])
+    return w2o.astype(np.float32), mat.astype(np.float32), light.astype(np.float32), kinds
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_vs_oracle(dev, seed):
+    """seeded sweep over what the boundary accepts: general affine shapes (Spheres and Squares),
+    ragged image sizes on either side of the tile-row heuristic, 1..3 samples with hash jitter,
+    Phong with / without specular and the depth shader, root and orbit camera.  Image against the
+    float64 oracle; gradients against it up to the float32 noise floor the oracle itself shows
+    when run in float32 at the same point (grazing rays)."""
+    rs = np.random.RandomState(1000 + seed)
+    w2o, mat, light, kinds = _random_scene(rs)
+    x = int(rs.choice([33, 64, 100, 130, 257]))
+    y = x if rs.rand() < 0.6 else int(rs.choice([48, 96, 192]))
+    A = int(rs.randint(1, 4))
+    shader = "depth" if seed % 4 == 3 else "phong"
+    kw = dict(x_dims=x, y_dims=y, antialias_samples=A, jitter=int(rs.randint(1, 1 << 20)), shader=shader,
+              specular=bool(rs.rand() < 0.7), max_depth=12.0)
+    if x != y or seed % 3 == 0:                               # the root camera of the reference only works for squares
+        kw["cam"] = synthetic_orbit_cam(float(rs.uniform(-0.5, 0.5)))
+    n_rows, n_cols = (y, x) if "cam" in kw else (x, y)
+    G = rs.randn(n_rows, n_cols, 3)
+    hi, hw, hm, hl = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **kw)
+    assert_image_close(hi, oi, "image")
+    # float32 noise floor of the same formulas
+    sd = O.sample_dist_from_uniform(O.hash_u01(kw["jitter"], y, x, A))
+    cam_o2w = None
+    if "cam" in kw:
+        cam_o2w = np.eye(4); cam_o2w[:3, :4] = np.asarray(kw["cam"][:12]).reshape(3, 4)
+    _, fw, fm, fl = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=x, y_dims=y, antialias_samples=A,
+                                       shader=shader, specular=kw["specular"], max_depth=12.0, cam_o2w=cam_o2w,
+                                       sample_dist=sd, dtype=torch.float32)
+    for got, ref, f32, what in ((hw, ow, fw.double().numpy(), "g_w2o"), (hm[:, :6], om[:, :6], fm.double().numpy()[:, :6],
+                                "g_material"), (hl, ol, fl.double().numpy(), "g_light")):
+        scale = max(np.abs(ref).max(), 1e-20)
+        err = np.abs(got - ref).max()
+        floor = np.abs(f32 - ref).max()
+        assert err <= max(GRAD_RTOL * scale, 4.0 * floor), "%s: err %g scale %g float32 floor %g" % (what, err, scale, floor)
+    assert np.isfinite(hm).all()
+
+
+def synthetic_orbit_cam(y):
+    from rrt import synthetic
+    return synthetic.orbit_camera(y)
