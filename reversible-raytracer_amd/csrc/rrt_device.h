@@ -487,6 +487,47 @@ RRT_HD bool cone_may_hit(const Cone<T>& c, const T cc[3], T R) {
   return !(cphi < cos_sum - T(1e-5));
 }
 
+// The same tile as a four-sided double pyramid: its rays are lines through the camera origin
+// with directions (u, w, 1), u in [u0,u1], w in [w0,w1].  A wave tile is 64 x P pixels, so the
+// circular cone above is up to 16x wider than the tile across its short side; the side planes
+// are what keeps shapes a few rows away out of the candidate set.
+template <class T>
+struct Frustum {
+  T u0, u1, w0, w1;       // widened by the reach of the jitter
+  T nu0, nu1, nw0, nw1;   // 1/|normal| of the planes x = u z and y = w z
+};
+
+template <class T>
+RRT_HD Frustum<T> tile_frustum(const ViewT<T>& v, int i0, int i1, int j0, int j1) {
+  T ua = T(0.5) + T(i0) * T(v.ustep), ub = T(0.5) + T(i1) * T(v.ustep);
+  T wa = T(-0.5) + T(j0) * T(v.vstep), wb = T(-0.5) + T(j1) * T(v.vstep);
+  Frustum<T> f;
+  f.u0 = ua < ub ? ua : ub; f.u1 = ua < ub ? ub : ua;
+  f.w0 = wa < wb ? wa : wb; f.w1 = wa < wb ? wb : wa;
+  // d = (u,w,1)/L + (sx/x_dims, sy/y_dims, 0), sx,sy in [0,1]  is the line (u + sx L/x_dims, w + sy L/y_dims, 1)
+  T um = m_abs<T>(f.u0) > m_abs<T>(f.u1) ? f.u0 : f.u1, wm = m_abs<T>(f.w0) > m_abs<T>(f.w1) ? f.w0 : f.w1;
+  T L = m_sqrt<T>(T(1) + um * um + wm * wm);
+  T eu = T(v.inv_xd) * L * T(1.01) + T(1e-6), ew = T(v.inv_yd) * L * T(1.01) + T(1e-6);
+  f.u0 -= eu; f.u1 += eu; f.w0 -= ew; f.w1 += ew;
+  f.nu0 = m_rsqrt<T>(T(1) + f.u0 * f.u0); f.nu1 = m_rsqrt<T>(T(1) + f.u1 * f.u1);
+  f.nw0 = m_rsqrt<T>(T(1) + f.w0 * f.w0); f.nw1 = m_rsqrt<T>(T(1) + f.w1 * f.w1);
+  return f;
+}
+
+// May any line of the pyramid touch the ball?  Conservative: false only when the ball AND its
+// mirror image (lines have no t > 0 test) each lie wholly outside one face of the half pyramid
+// z >= 0.  NaN / infinite radii never cull.
+template <class T>
+RRT_HD bool frustum_may_hit(const Frustum<T>& f, const T cc[3], T R) {
+  const T x = cc[0], y = cc[1], z = cc[2];
+  const T R1 = R * T(1.001) + T(1e-5) * (m_abs<T>(x) + m_abs<T>(y) + m_abs<T>(z) + T(1));
+  const T a1 = (x - f.u1 * z) * f.nu1, a0 = (f.u0 * z - x) * f.nu0;     // > R1: outside that face
+  const T b1 = (y - f.w1 * z) * f.nw1, b0 = (f.w0 * z - y) * f.nw0;
+  const bool out_pos = a1 > R1 || a0 > R1 || b1 > R1 || b0 > R1 || -z > R1;
+  const bool out_neg = -a1 > R1 || -a0 > R1 || -b1 > R1 || -b0 > R1 || z > R1;
+  return !(out_pos && out_neg);
+}
+
 // ---------------------------------------------------- setup and finalize --
 // Pack one shape for one scene: fold the camera into the shape transform,
 // precompute the per-shape constants and a bounding ball for the tile cull.

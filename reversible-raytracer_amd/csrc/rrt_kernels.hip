@@ -388,6 +388,7 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
     pixel_to_ray(a.v, t.a0 + a.v.row0, t.b0, i0, j0);
     pixel_to_ray(a.v, t.a0 + t.nrows - 1 + a.v.row0, t.b0 + t.ncols - 1, i1, j1);
     Cone<float> cone = tile_cone<float>(a.v, i0, i1, j0, j1);
+    Frustum<float> fr = tile_frustum<float>(a.v, i0, i1, j0, j1);
     unsigned long long m = 0;
     int cur = 0;                                 // mask word being assembled
     for (int q = 0; q < n; ++q) {
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
       if (!nocull) {
         float4 ball = s_ball[q];
         float cc[3] = {ball.x, ball.y, ball.z};
-        c = cone_may_hit<float>(cone, cc, ball.w);
+        c = cone_may_hit<float>(cone, cc, ball.w) && frustum_may_hit<float>(fr, cc, ball.w);
       }
       m |= (unsigned long long)c << (k & 63);
       if (c) { if (!n_cand) k_first = k; ++n_cand; }

@@ -206,10 +206,12 @@ int64_t harness_cull_check(int S, const float* w2o, const float* mat, const floa
       pixel_to_ray(v, a0 + v.row0, b0, i0, j0);
       pixel_to_ray(v, a1 + v.row0, b1, i1, j1);
       Cone<float> cone = tile_cone<float>(v, i0, i1, j0, j1);
+      Frustum<float> fr = tile_frustum<float>(v, i0, i1, j0, j1);
       std::vector<char> cand(S);
       for (int k = 0; k < S; ++k) {
         const float* p = pk.ps.data() + (size_t)k * PS_STRIDE;
-        cand[k] = cone_may_hit<float>(cone, p + PS_CULL_C, p[PS_CULL_R]);
+        cand[k] = cone_may_hit<float>(cone, p + PS_CULL_C, p[PS_CULL_R]) &&
+                  frustum_may_hit<float>(fr, p + PS_CULL_C, p[PS_CULL_R]);
         cand_sum += cand[k];
       }
       ++tiles;
