@@ -56,7 +56,9 @@ typedef enum rrt_status {
 
 /* Anti-alias jitter source for scene.py:24-32.
  *   CENTER   U = 0.5 for every (pixel, sample)            (deterministic)
- *   EXPLICIT caller supplies sampleDist_x/_y               (parity runs)
+ *   EXPLICIT caller supplies sampleDist_x/_y               (parity runs); values must lie in
+ *            [0, 1] as the reference's (U + sample) / A do -- the tile cull bounds a tile's
+ *            rays with that reach (pass RRT_FLAG_NO_CULL for anything else)
  *   HASH     U = counter hash of (seed, i, j, sample, axis) (reproducible
  *            stand-in for the reference's unseeded np.random.random) */
 #define RRT_JITTER_CENTER 0
