@@ -53,13 +53,37 @@ def parse():
                          "c3: match_mirror scene (2 spheres + square) 1024^2, A=4; c5: 256 orbit scenes of 64^2, A=4")
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline band (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the fixed --size^2 image cut into N row bands (BASELINE configs[3]); "
+                         "weak = --size rows PER GPU (the image grows to N*size x size rays)")
     return ap.parse_args()
+
+
+def relaunch_as_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks (one process per GPU, RCCL) with
+    ``torch.distributed.run`` BEFORE this process touches the GPU, relay their output (rank 0 prints the
+    JSON line) and exit with their status.  Never falls back to fewer GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # counts devices without initialising the GPU
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; refusing to run on fewer" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 class Job(object):
     """Direct C-ABI driver (no autograd in the timed region)."""
 
-    def __init__(self, dev, size, spheres, aa, row0, rows, cull, workload="c4"):
+    def __init__(self, dev, size, spheres, aa, row0, rows, cull, workload="c4", full_rows=None):
         from rrt import _native as N
         from rrt import synthetic
         self.N = N
@@ -98,7 +122,8 @@ class Job(object):
 
         def view(flags):
             vw = N.RrtView()
-            vw.x_dims = vw.y_dims = size
+            # root camera (transpose = 1): image axis 0 runs over x_dims, axis 1 over y_dims
+            vw.x_dims, vw.y_dims = (full_rows or size), size
             vw.antialias_samples = aa
             vw.row0, vw.rows = row0, rows
             vw.shader_id, vw.specular, vw.transpose = N.SHADER_PHONG, specular, transpose
@@ -198,7 +223,13 @@ def parity_sample(dev, size, spheres, aa, rows=48):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_as_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: they must agree" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -217,8 +248,10 @@ def main():
         args.size, args.aa = 1024, 4
     elif args.workload == "c5":
         args.size, args.aa = 64, 4
-    row0, rows = band(args.size, rank, world)
-    job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull, args.workload)
+    # strong: the size x size image in `world` row bands; weak: `size` rows per rank of a (world*size) x size image
+    full_rows = args.size * world if args.scaling == "weak" else args.size
+    row0, rows = band(full_rows, rank, world)
+    job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull, args.workload, full_rows=full_rows)
     args.spheres = job.S
 
     # upstream gradient of the match_mirror loss, computed once: g = 2 (image - fliplr(image0))
@@ -251,7 +284,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
-    rays = job.B * args.size * args.size * args.aa
+    rays = job.B * full_rows * args.size * args.aa
     value = rays / (elapsed / args.steps) / 1e6
 
     # per-kernel durations, HIP events on the launch stream (torch's current stream)
@@ -307,13 +340,13 @@ def main():
             cpu = cpu_baseline(args.size, args.spheres, args.aa, args.cpu_rows)
             parity = parity_sample(dev, args.size, args.spheres, args.aa)
         out = {
-            "metric": "Mrays/s fwd+bwd at %dx%d/%d spheres" % (args.size, args.size, args.spheres),
+            "metric": "Mrays/s fwd+bwd at %dx%d/%d spheres" % (full_rows, args.size, args.spheres),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"c4": "%d random spheres (seed 0), %dx%d, antialias_samples=%d, Phong+specular, "
-                                          "root camera, dense upstream grad; row bands over %d GPU(s)"
-                                          % (args.spheres, args.size, args.size, args.aa, world),
+                                          "root camera, dense upstream grad; %d row band(s) of %d rows, one per GPU"
+                                          % (args.spheres, full_rows, args.size, args.aa, world, rows),
                                     "c2": "config 2: 1 sphere Phong, 512x512, antialias_samples=1",
                                     "c3": "config 3: match_mirror.py scene (2 spheres + square), 1024x1024, "
                                           "antialias_samples=4, hash jitter",

@@ -290,9 +290,16 @@ def normed_dir(direction):
     return d / torch.sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
 
 
-def phong_shade(kind, rays, origin, material, light, look_at, specular=True):
+def phong_shade(kind, rays, origin, material, light, look_at, specular=True, shininess_grad="theano"):
     """shader.py:28-53 (specular=False: orbit_experiments/shader.py:45,48).
-    material = (r,g,b,ks,kd,ka,shininess); light = (dir xyz, intensity rgb)."""
+    material = (r,g,b,ks,kd,ka,shininess); light = (dir xyz, intensity rgb).
+
+    shininess_grad: what d/dshininess means.  "theano" = the literal chain rule
+    of ``base ** shininess`` (``log(base) * pow``: NaN as soon as one lane has a
+    negative base -- what T.grad would hand back).  "masked" = the product's
+    documented extension (include/rrt.h): lanes with a non-positive base
+    contribute 0 to d/dshininess; values and every other gradient are
+    unchanged."""
     color, ks, kd, ka, sh = material[0:3], material[3], material[4], material[5], material[6]
     L = normed_dir(light[0:3])
     intensity = light[3:6]
@@ -302,7 +309,14 @@ def phong_shade(kind, rays, origin, material, light, look_at, specular=True):
     phong = ka + diffuse
     if specular:
         rm = 2.0 * ndotl[:, :, None] * normals + L
-        phong = phong + ks * torch.pow(torch.tensordot(rm, look_at, dims=1), sh)
+        base = torch.tensordot(rm, look_at, dims=1)
+        if shininess_grad == "masked":
+            pos = base > 0
+            safe = torch.where(pos, base, torch.ones_like(base))
+            powv = torch.where(pos, torch.exp(sh * torch.log(safe)), torch.pow(base, sh.detach()))
+        else:
+            powv = torch.pow(base, sh)
+        phong = phong + ks * powv
     colorized = phong[:, :, None] * color[None, None, :] * intensity[None, None, :]
     clipped = torch.clamp(colorized, 0, 1)
     distances = shape_distance(kind, rays, origin)
@@ -323,7 +337,7 @@ def depth_shade(kind, rays, origin, max_depth):
 def render(w2o, material, light, kinds=None, *, x_dims, y_dims,
            antialias_samples=4, shader="phong", specular=True, max_depth=1.0,
            cam_o2w=None, look_at=(0.0, 0.0, 1.0), sample_dist=None,
-           row0=0, rows=None, dtype=torch.float64):
+           row0=0, rows=None, dtype=torch.float64, shininess_grad="theano"):
     """scene.py:18-52 (``Scene.build``), orbit camera orbit_experiments/scene.py:56-80.
 
     w2o        [S,4,4] (or [S,3,4]) world->object matrices (``shape.w2o.m``)
@@ -390,7 +404,7 @@ def render(w2o, material, light, kinds=None, *, x_dims, y_dims,
             dists = shape_distance(kinds[k], r_k, o_k)
             if shader == "phong":
                 shadings = phong_shade(kinds[k], r_k, o_k, material[k], light, look,
-                                       specular=specular)
+                                       specular=specular, shininess_grad=shininess_grad)
             else:
                 shadings = depth_shade(kinds[k], r_k, o_k, max_depth)
             if image_per_sample is None:

@@ -44,7 +44,9 @@ constexpr int PS_KD = 17;
 constexpr int PS_KA = 18;
 constexpr int PS_SH = 19;
 constexpr int PS_KIND = 20;   //      RRT_KIND_* (ps_store_int / ps_load_int)
-constexpr int PS_POWF = 21;   //      POW_* flags of the shininess (ps_store_int / ps_load_int)
+constexpr int PS_POWF = 21;   //      POW_* / FAST_* flags (ps_store_int / ps_load_int)
+constexpr int PS_CMAX = 22;   //      max_j colI_j           (fast paths: one compare finds a wave without upper clipping)
+constexpr int PS_KSSH = 23;   //      ks * shininess         (fast adjoint)
 constexpr int PS_CULL_C = 24; // [3]  centre of a bounding ball, camera-local
 constexpr int PS_CULL_R = 27; //      its radius (inf = never cull)
 
@@ -53,6 +55,7 @@ constexpr int HDR_STRIDE = 32;
 constexpr int HDR_LHAT = 0;   // [3]  normed light direction (scene.py:83-86)
 constexpr int HDR_LOOK = 3;   // [3]  camera.look_at
 constexpr int HDR_INVLN = 6;  //      1/|L|
+constexpr int HDR_LLOOK = 7;  //      Lhat . look_at   (s = rm . look_at = Lhat.look_at + 2 dd (n . look_at))
 constexpr int HDR_CAM = 8;    // [9]  camera o2w linear part, row-major
 constexpr int HDR_CAMO = 17;  // [3]  camera origin
 
@@ -78,6 +81,12 @@ constexpr int JITTER_HASH = 2;
 
 constexpr int POW_INT = 1;   // shininess is integer valued
 constexpr int POW_ODD = 2;   // ... and odd
+// A shape whose render can take the lean code paths (shade_phong_fast / adjoint_sphere_phong):
+// a Sphere with colour * intensity > 0 on every channel (then clip(phi colI_j, 0, 1) is clipped
+// at 0 on ALL channels exactly when phi < 0); with the specular term also shininess > 1 (then
+// |s|^(sh-1) is finite at s = 0 and the special cases of pow() at exponent 0 and 1 do not arise).
+constexpr int FAST_NOSPEC = 4;
+constexpr int FAST_SPEC = 8;
 
 // ------------------------------------------------------------ math shims --
 template <class T> RRT_HD T m_sqrt(T x) { return sqrt(x); }
@@ -98,6 +107,23 @@ template <> RRT_HD float m_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(
 template <> RRT_HD float m_log2<float>(float x) { return __builtin_amdgcn_logf(x); }
 template <> RRT_HD float m_exp2<float>(float x) { return __builtin_amdgcn_exp2f(x); }
 template <> RRT_HD float m_abs<float>(float x) { return __builtin_fabsf(x); }
+#endif
+
+// |x| if c else x ; e (>= 0 or NaN) with the sign of s if c else e.  c is wave-uniform on the GPU, where
+// both are one bit operation with a scalar mask instead of a compare + select.
+template <class T> RRT_HD T abs_if(T x, bool c) { return c ? m_abs<T>(x) : x; }
+template <class T> RRT_HD T sign_of_if(T e, T s, bool c) { return (c && s < T(0)) ? -e : e; }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> RRT_HD float abs_if<float>(float x, bool c) {
+  return __uint_as_float(__float_as_uint(x) & (c ? 0x7fffffffu : 0xffffffffu));
+}
+template <> RRT_HD float sign_of_if<float>(float e, float s, bool c) {
+  return __uint_as_float(__float_as_uint(e) | (__float_as_uint(s) & (c ? 0x80000000u : 0u)));
+}
+// does the predicate hold on any active lane of the wave?
+#define RRT_WAVE_ANY(c) (__ballot(c) != 0ull)
+#else
+#define RRT_WAVE_ANY(c) (c)
 #endif
 
 // Small ints inside the packed float record: bit pattern for float storage (so
@@ -155,14 +181,31 @@ RRT_HD void sample_dist(const ViewT<T>& v, const float* jitter, int i, int j, in
 
 // Camera.make_rays (scene.py:66-74): d = normalize(u_i, v_j, 1) then
 // d.x += sdx/x_dims, d.y += sdy/y_dims (jitter AFTER normalisation).
+//
+// Split so that the kernels keep what depends only on a lane's own grid coordinate out of
+// their row loops: with cl the coordinate that varies along image columns (u under the root
+// camera's transpose, w otherwise) and cr the one that varies along rows,
+//   1/|(u, w, 1)| = rsqrt(cr^2 + (cl^2 + 1)),   q = cl^2 + 1 is per lane and tile.
+// jx, jy = sampleDist / dims.  Every caller (kernels, CPU harness) goes through ray_dir_parts,
+// so a ray has the same bits whichever kernel, tile shape or row band generates it.
+template <class T>
+RRT_HD T grid_u(const ViewT<T>& v, int i) { return T(0.5) + T(i) * T(v.ustep); }
+template <class T>
+RRT_HD T grid_w(const ViewT<T>& v, int j) { return T(-0.5) + T(j) * T(v.vstep); }
+
+template <class T>
+RRT_HD void ray_dir_parts(T u, T w, T q, T cr, T jx, T jy, T d[3]) {
+  T inv = m_rsqrt<T>(cr * cr + q);
+  d[0] = u * inv + jx;
+  d[1] = w * inv + jy;
+  d[2] = inv;
+}
+
 template <class T>
 RRT_HD void ray_dir(const ViewT<T>& v, int i, int j, T sdx, T sdy, T d[3]) {
-  T u = T(0.5) + T(i) * T(v.ustep);
-  T w = T(-0.5) + T(j) * T(v.vstep);
-  T inv = m_rsqrt<T>(u * u + w * w + T(1));
-  d[0] = u * inv + sdx * T(v.inv_xd);
-  d[1] = w * inv + sdy * T(v.inv_yd);
-  d[2] = inv;
+  T u = grid_u<T>(v, i), w = grid_w<T>(v, j);
+  T cl = v.transpose ? u : w, cr = v.transpose ? w : u;
+  ray_dir_parts<T>(u, w, cl * cl + T(1), cr, sdx * T(v.inv_xd), sdy * T(v.inv_yd), d);
 }
 
 // Output pixel (a,b) of the image window -> ray grid index (i,j).
@@ -310,6 +353,29 @@ RRT_HD void shade_phong(const T nu[3], const T colI[3], T ks, T kd, T ka, T sh, 
   }
 }
 
+// The same for a FAST_* shape (colI > 0 on every channel; with the specular term shininess > 1),
+// leaner: s = rm . look_at = Lhat.look_at + 2 dd (n . look_at) instead of building rm; pow() as one
+// log2 / exp2 with the sign handled by bit masks (no exponent-0 / exponent-1 / zero-base cases to
+// select between: with shininess > 0 a zero base gives exp2(-inf) = 0).
+template <class T, int SPEC>
+RRT_HD void shade_phong_fast(const T nu[3], const T colI[3], T ks, T kd, T ka, T sh, int powf,
+                             const T L[3], const T look[3], T Llook, T c[3]) {
+  T inv = m_rsqrt<T>(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]);
+  T n0 = nu[0] * inv, n1 = nu[1] * inv, n2 = nu[2] * inv;
+  T ndl = n0 * L[0] + n1 * L[1] + n2 * L[2];            // dd = -ndl
+  T phi = ka - kd * ndl;
+  if (SPEC) {
+    T nlk = n0 * look[0] + n1 * look[1] + n2 * look[2];
+    T s = Llook - (ndl + ndl) * nlk;
+    T e = m_exp2<T>(sh * m_log2<T>(abs_if<T>(s, (powf & POW_INT) != 0)));   // non-integer shininess: log2 of s < 0 is NaN, as pow()
+    phi += ks * sign_of_if<T>(e, s, (powf & POW_ODD) != 0);
+  }
+  for (int q = 0; q < 3; ++q) {
+    T x = phi * colI[q];
+    c[q] = x < T(0) ? T(0) : (x > T(1) ? T(1) : x);       // NaN passes through like T.clip
+  }
+}
+
 // DepthMapShader.shade (shader.py:14-20): 1 - t/maxDepth on all channels.
 template <class T>
 RRT_HD T shade_depth(T t, T inv_max_depth) { return T(1) - t * inv_max_depth; }
@@ -428,6 +494,107 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
     acc[ACC_O + q] += g_o[q];
   }
   return true;
+}
+
+// The hot path of the adjoint: a FAST_* Sphere under the Phong shader (see FAST_NOSPEC / FAST_SPEC).
+// Same mathematics as adjoint_ray, organised for the VALU:
+//   * colI > 0  =>  every channel is clipped at 0 exactly when phi < 0: such a ray (and a NaN phi,
+//     whose clip masks are all false) contributes nothing and leaves with the misses; the upper
+//     clip is tested once per wave on the brightest channel (cmax) and only a wave that has a
+//     saturated lane builds per-channel masks;
+//   * s = Lhat.look + 2 dd (n.look): rm is never built, and g_rm . n = g_s (n.look) reuses n.look;
+//   * |s|^(sh-1) by one log2 / exp2, sign by bit masks, |s|^sh = |s|^(sh-1) s  (shininess > 1: no
+//     special cases; non-integer shininess with s < 0 gives NaN like pow());
+//   * g_n = c1 look - g_dd Lhat and G_Lhat = g_s look - g_dd n straight from scalars.
+// kssh = ks * shininess, shm1 = shininess - 1, Llook = Lhat . look_at, cmax = max_j colI_j.
+// Returns whether the ray contributed.
+template <class T, int SPEC>
+RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cmax, T ks, T kd, T ka, T shm1, T kssh,
+                                 int powf, const T L[3], const T look[3], T Llook, const T d[3], const T up[3],
+                                 T* acc) {
+  T r[3];
+  xform_dir<T>(A, d, r);
+  const T alpha = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const T beta = r[0] * o[0] + r[1] * o[1] + r[2] * o[2];
+  const T ia = m_rcp<T>(alpha);
+  const T q = beta * ia;
+  const T op[3] = {o[0] - q * r[0], o[1] - q * r[1], o[2] - q * r[2]};
+  const T Dp = T(1) - (op[0] * op[0] + op[1] * op[1] + op[2] * op[2]);
+  if (!(Dp > T(0))) return false;                             // miss (or NaN) => exactly zero
+  const T x = Dp * ia;
+  const T ih = m_rsqrt<T>(x);
+  const T h = x * ih;
+  const T t = -q - h;
+  const T nu[3] = {op[0] - h * r[0], op[1] - h * r[1], op[2] - h * r[2]};
+  const T inv = m_rsqrt<T>(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]);
+  const T n[3] = {nu[0] * inv, nu[1] * inv, nu[2] * inv};
+  const T ndl = n[0] * L[0] + n[1] * L[1] + n[2] * L[2];      // dd = -ndl
+  T phi = ka - kd * ndl;
+  T nlk = T(0), s = T(0), p1 = T(0), pw = T(0), l2 = T(0);
+  if (SPEC) {
+    nlk = n[0] * look[0] + n[1] * look[1] + n[2] * look[2];
+    s = Llook - (ndl + ndl) * nlk;
+    l2 = m_log2<T>(abs_if<T>(s, (powf & POW_INT) != 0));
+    p1 = sign_of_if<T>(m_exp2<T>(shm1 * l2), s, (powf & (POW_INT | POW_ODD)) == POW_INT);   // sign(s)^(sh-1)
+    pw = p1 * s;
+    phi += ks * pw;
+  }
+  if (!(phi >= T(0))) return false;                           // all three channels clipped at 0 (or NaN)
+  T um[3] = {up[0], up[1], up[2]};
+  if (RRT_WAVE_ANY(phi * cmax > T(1))) {
+    for (int c = 0; c < 3; ++c) um[c] = (phi * colI[c] <= T(1)) ? up[c] : T(0);
+  }
+  const T g_phi = um[0] * colI[0] + um[1] * colI[1] + um[2] * colI[2];
+  acc[ACC_COLI + 0] += um[0] * phi;
+  acc[ACC_COLI + 1] += um[1] * phi;
+  acc[ACC_COLI + 2] += um[2] * phi;
+  acc[ACC_KA] += g_phi;
+  acc[ACC_KD] -= g_phi * ndl;
+  T g_dd = g_phi * kd;
+  T g_n[3];
+  if (SPEC) {
+    acc[ACC_KS] += g_phi * pw;
+    // d/dshininess = pw ln(s), lanes with s <= 0 contribute 0 (extension, see rrt.h)
+    const T l2p = (s > T(0)) ? l2 : T(0);
+    acc[ACC_SH] += (g_phi * ks) * pw * (l2p * T(0.6931471805599453));
+    const T g_s = (g_phi * kssh) * p1;
+    const T g_s2 = g_s + g_s;
+    g_dd += g_s2 * nlk;                                       // rm = 2 dd n + Lhat:  g_dd += 2 g_rm . n,  g_rm = g_s look
+    const T c1 = -ndl * g_s2;                                 // g_n = 2 dd g_rm - g_dd Lhat
+    for (int c = 0; c < 3; ++c) {
+      g_n[c] = c1 * look[c] - g_dd * L[c];
+      acc[ACC_LHAT + c] += g_s * look[c] - g_dd * n[c];       // G_Lhat += g_rm - g_dd n
+    }
+  } else {
+    for (int c = 0; c < 3; ++c) {
+      g_n[c] = -g_dd * L[c];
+      acc[ACC_LHAT + c] -= g_dd * n[c];
+    }
+  }
+  // n = p/|p|
+  const T ndg = n[0] * g_n[0] + n[1] * g_n[1] + n[2] * g_n[2];
+  const T g_p[3] = {(g_n[0] - n[0] * ndg) * inv, (g_n[1] - n[1] * ndg) * inv, (g_n[2] - n[2] * ndg) * inv};
+  const T g_t = g_p[0] * r[0] + g_p[1] * r[1] + g_p[2] * r[2];
+  // t = t(r', o'), collected as in adjoint_ray (only well conditioned quantities appear)
+  const T gta = g_t * ia;
+  const T gD2 = -gta * ia * ih;                               // 2 g_D,  sqrt(Delta) = alpha h
+  const T ca = gD2 * alpha;
+  const T cr = gD2 * Dp - (gta + gta) * t;
+  const T cop = gD2 * beta;
+  for (int c = 0; c < 3; ++c) {
+    const T g_o = g_p[c] - gta * r[c] - ca * op[c];
+    const T g_r = t * g_p[c] - gta * o[c] + cr * r[c] + cop * op[c];
+    acc[ACC_RD + 3 * c + 0] += g_r * d[0];
+    acc[ACC_RD + 3 * c + 1] += g_r * d[1];
+    acc[ACC_RD + 3 * c + 2] += g_r * d[2];
+    acc[ACC_O + c] += g_o;
+  }
+  return true;
+}
+
+// Which of the two a (shape, view) pair takes; the kernels and the CPU harness both dispatch on it.
+RRT_HD bool adjoint_is_fast(int kind, int powf, int shader, int specular) {
+  return kind == KIND_SPHERE && shader == SHADER_PHONG && (powf & (specular ? FAST_SPEC : FAST_NOSPEC)) != 0;
 }
 
 // ------------------------------------------------------------- tile cull --
@@ -562,9 +729,18 @@ RRT_HD void pack_shape(const float* w2o, const float* cam, const float* mat, con
   } else if (fabsf(sh) >= 16777216.0f && sh == sh) {
     powf |= POW_INT;   // every float this large is an even integer
   }
+  {
+    const T c0 = T(mat[0]) * T(light[3]), c1 = T(mat[1]) * T(light[4]), c2 = T(mat[2]) * T(light[5]);
+    const T cmax = c0 > c1 ? (c0 > c2 ? c0 : c2) : (c1 > c2 ? c1 : c2);
+    if (kind == KIND_SPHERE && c0 > T(0) && c1 > T(0) && c2 > T(0) && cmax < T(1e30)) {
+      powf |= FAST_NOSPEC;
+      if (sh > 1.0f && sh < 1e30f) powf |= FAST_SPEC;
+    }
+    ps[PS_CMAX] = (ST)cmax;
+    ps[PS_KSSH] = (ST)(T(mat[3]) * T(mat[6]));
+  }
   ps[PS_KIND] = ps_store_int(kind, ST(0));
   ps[PS_POWF] = ps_store_int(powf, ST(0));
-  ps[22] = ST(0); ps[23] = ST(0);
   // bounding ball in camera-local space: x = A'^-1 (y - o'), |y| <= rho
   T c00 = Ap[4] * Ap[8] - Ap[5] * Ap[7], c01 = Ap[5] * Ap[6] - Ap[3] * Ap[8], c02 = Ap[3] * Ap[7] - Ap[4] * Ap[6];
   T det = Ap[0] * c00 + Ap[1] * c01 + Ap[2] * c02;
@@ -608,6 +784,7 @@ RRT_HD void pack_header(const float* cam, const float* light, ST* hdr) {
     for (int c = 0; c < 3; ++c) hdr[HDR_CAM + 3 * q + c] = (ST)cam[4 * q + c];
   }
   hdr[HDR_INVLN] = (ST)inv;
+  hdr[HDR_LLOOK] = (ST)((L[0] * T(cam[12]) + L[1] * T(cam[13]) + L[2] * T(cam[14])) * inv);
 }
 
 // Chain one accumulator row back to the raw parameters of its shape:

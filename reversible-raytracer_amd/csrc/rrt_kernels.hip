@@ -193,6 +193,7 @@ __device__ __forceinline__ unsigned long long lane_bcast64(unsigned long long v,
 // One shape's packed record as wave-uniform scalars (SGPRs).
 struct ShapeP {
   float A[9], o[3], colI[3], ks, kd, ka, sh;
+  float cmax, kssh;               // max colI, ks * sh (the FAST_* code paths)
   int kind, powf;
 };
 
@@ -210,6 +211,7 @@ __device__ __forceinline__ void load_shape(const KArgs& a, const float* lds, int
     q.ks = lane_bcast(v, PS_KS); q.kd = lane_bcast(v, PS_KD); q.ka = lane_bcast(v, PS_KA); q.sh = lane_bcast(v, PS_SH);
     q.kind = ps_load_int(lane_bcast(v, PS_KIND));
     q.powf = ps_load_int(lane_bcast(v, PS_POWF));
+    q.cmax = lane_bcast(v, PS_CMAX); q.kssh = lane_bcast(v, PS_KSSH);
   } else {
     cfptr r = as_const(a.ps) + ((size_t)b * a.S + k) * PS_STRIDE;
 #pragma unroll
@@ -219,7 +221,40 @@ __device__ __forceinline__ void load_shape(const KArgs& a, const float* lds, int
     q.ks = r[PS_KS]; q.kd = r[PS_KD]; q.ka = r[PS_KA]; q.sh = r[PS_SH];
     q.kind = ps_load_int(r[PS_KIND]);
     q.powf = ps_load_int(r[PS_POWF]);
+    q.cmax = r[PS_CMAX]; q.kssh = r[PS_KSSH];
   }
+}
+
+// The transform of a shape as per-lane VGPR copies (every lane reads the same LDS words: three
+// broadcast ds_read_b128, A' and o' are the first 12 words of the record).
+__device__ __forceinline__ void load_shape_vgpr(const KArgs& a, const float* lds, int b, int k, const ShapeP& q,
+                                                float Av[9], float ov[3]) {
+  if (a.lds_scene) {
+    const float4* r = reinterpret_cast<const float4*>(lds + ((size_t)b * a.S + k) * PS_STRIDE);
+    const float4 x0 = r[0], x1 = r[1], x2 = r[2];
+    Av[0] = x0.x; Av[1] = x0.y; Av[2] = x0.z; Av[3] = x0.w; Av[4] = x1.x; Av[5] = x1.y; Av[6] = x1.z; Av[7] = x1.w;
+    Av[8] = x2.x; ov[0] = x2.y; ov[1] = x2.z; ov[2] = x2.w;
+  } else {
+#pragma unroll
+    for (int n = 0; n < 9; ++n) Av[n] = q.A[n];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) ov[n] = q.o[n];
+  }
+#pragma unroll
+  for (int n = 0; n < 9; ++n) asm volatile("" : "+v"(Av[n]));
+#pragma unroll
+  for (int n = 0; n < 3; ++n) asm volatile("" : "+v"(ov[n]));
+}
+
+// Per-scene shading constants (wave-uniform): normed light direction, look_at, their dot product.
+struct SceneP {
+  float L[3], look[3], Llook;
+};
+__device__ __forceinline__ void load_scene(const KArgs& a, int b, SceneP& sc) {
+  cfptr hdr = as_const(a.hdr) + (size_t)b * HDR_STRIDE;
+#pragma unroll
+  for (int n = 0; n < 3; ++n) { sc.L[n] = hdr[HDR_LHAT + n]; sc.look[n] = hdr[HDR_LOOK + n]; }
+  sc.Llook = hdr[HDR_LLOOK];
 }
 
 __device__ __forceinline__ void stage_scene(const KArgs& a, float* lds) {
@@ -230,19 +265,52 @@ __device__ __forceinline__ void stage_scene(const KArgs& a, float* lds) {
   __syncthreads();       // the only workgroup barrier of the render kernels (once, before the tile loop)
 }
 
-// Ray directions of this lane's P pixels for sample s.
-template <int P>
-__device__ __forceinline__ void gen_rays(const KArgs& a, const Tile& t, int lane, int s, float d[P][3]) {
-  const int col = t.b0 + min(lane, t.ncols - 1);
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int row = t.a0 + min(p, t.nrows - 1);
+// Ray generation, split so that what depends only on the lane stays out of the row loops
+// (rrt_device.h: ray_dir_parts).  LaneRay: the lane's own grid coordinate cl (u under the root
+// camera's transpose, w otherwise), q = cl^2 + 1 and its clamped image column.
+struct LaneRay {
+  float cl, q;
+  int col;
+};
+template <int TR>
+__device__ __forceinline__ LaneRay lane_ray(const KArgs& a, const Tile& t, int lane) {
+  LaneRay lr;
+  lr.col = t.b0 + min(lane, t.ncols - 1);
+  lr.cl = TR ? grid_u<float>(a.v, lr.col) : grid_w<float>(a.v, lr.col);
+  lr.q = lr.cl * lr.cl + 1.0f;
+  return lr;
+}
+// sample s of the pixel in window row `row` (JC: jitter at the stratum centre -- jc = sampleDist / dims,
+// the same for every pixel, is passed in; otherwise hash or explicit jitter per ray; TR = view.transpose)
+template <int JC, int TR>
+__device__ __forceinline__ void row_ray(const KArgs& a, const LaneRay& lr, int row, int s, float jcx, float jcy,
+                                        float d[3]) {
+  const ViewK& v = a.v;
+  const int ra = row + v.row0;
+  const float cr = TR ? grid_w<float>(v, ra) : grid_u<float>(v, ra);
+  float jx = jcx, jy = jcy;
+  if (!JC) {
     int i, j;
-    pixel_to_ray(a.v, row + a.v.row0, col, i, j);
+    pixel_to_ray(v, ra, lr.col, i, j);
     float sdx, sdy;
-    sample_dist<float>(a.v, a.jitter, i, j, s, sdx, sdy);
-    ray_dir<float>(a.v, i, j, sdx, sdy, d[p]);
+    sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
+    jx = sdx * v.inv_xd;
+    jy = sdy * v.inv_yd;
   }
+  ray_dir_parts<float>(TR ? lr.cl : cr, TR ? cr : lr.cl, lr.q, cr, jx, jy, d);
+}
+__device__ __forceinline__ void centre_jitter(const ViewK& v, int s, float& jcx, float& jcy) {
+  const float sd = (0.5f + (float)s) * v.inv_A;      // sample_dist(JITTER_CENTER)
+  jcx = sd * v.inv_xd;
+  jcy = sd * v.inv_yd;
+}
+
+template <int P, int JC, int TR>
+__device__ __forceinline__ void gen_rays(const KArgs& a, const Tile& t, const LaneRay& lr, int s, float d[P][3]) {
+  float jcx, jcy;
+  centre_jitter(a.v, s, jcx, jcy);
+#pragma unroll
+  for (int p = 0; p < P; ++p) row_ray<JC, TR>(a, lr, t.a0 + min(p, t.nrows - 1), s, jcx, jcy, d[p]);
 }
 
 // One candidate against this lane's P rays (scene.py:38-47: strict '<', the
@@ -629,6 +697,19 @@ __device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, un
 #define RRT_FWD_WAVES_PER_SIMD 4
 #endif
 
+// Colour of one winning hit: FAST_* shapes (rrt_device.h) take the lean Phong path (wave-uniform branch).
+template <int SHADER, int SPEC>
+__device__ __forceinline__ void shade_hit(const KArgs& a, const ShapeP& q, const SceneP& sc, float tmin,
+                                          const float nu[3], float x[3]) {
+  if (SHADER == SHADER_DEPTH) {
+    x[0] = x[1] = x[2] = shade_depth<float>(tmin, a.v.inv_max_depth);
+  } else if (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC)) {
+    shade_phong_fast<float, SPEC>(nu, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, sc.L, sc.look, sc.Llook, x);
+  } else {
+    shade_phong<float>(nu, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SPEC, sc.L, sc.look, x);
+  }
+}
+
 // ---------------------------------------------------------------- forward --
 // Persistent, one 1024-thread workgroup per CU.  The workgroup's share of the "has
 // candidates" list (an equal part of every cost class, expensive first) and of the "none"
@@ -636,7 +717,7 @@ __device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, un
 // tiles to zero-fill, so the store stream runs under the arithmetic and no wave idles
 // behind an unlucky static deal (a wave timeline -- tools/stamp_fwd.py -- showed a third of
 // a statically dealt wave's life in the list prologue and an 11 us tail).
-template <int P, int SHADER, int SPEC>
+template <int P, int SHADER, int SPEC, int JC, int TR>
 __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   __shared__ WgQueue s_q;
@@ -680,7 +761,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
   };
 
   int b_cur = -1;
-  float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
+  SceneP sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
   QueueState qs;
   qs.next = qs.next_e = blockIdx.x;
   for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
@@ -711,11 +792,11 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
       int k0; bool multi; long long tile;
       const Tile t = decode_entry(a, e_cur, k0, multi, tile);
       if (t.b != b_cur) {
-        cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
-        for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
+        load_scene(a, t.b, sc);
         b_cur = t.b;
       }
       cuptr mk = as_const(a.mask) + tile * a.nwords;
+      const LaneRay lr = lane_ray<TR>(a, t, lane);
       float c[P][3];
 #pragma unroll
       for (int p = 0; p < P; ++p) c[p][0] = c[p][1] = c[p][2] = 0.f;
@@ -723,7 +804,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
       for (int s = 0; s < v.A; ++s) {
         float d[P][3], tmin[P], nu[P][3];
         int best[P];
-        gen_rays<P>(a, t, lane, s, d);
+        gen_rays<P, JC, TR>(a, t, lr, s, d);
 #pragma unroll
         for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
         if (!multi) {
@@ -735,8 +816,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
           for (int p = 0; p < P; ++p) {
             if (best[p] >= 0) {
               float x[3];
-              if (SHADER == SHADER_DEPTH) x[0] = x[1] = x[2] = shade_depth<float>(tmin[p], v.inv_max_depth);
-              else shade_phong<float>(nu[p], q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SPEC, L, look, x);
+              shade_hit<SHADER, SPEC>(a, q, sc, tmin[p], nu[p], x);
               c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
             }
           }
@@ -776,7 +856,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
                 for (int p = 0; p < P; ++p) {
                   if (best[p] == k) {
                     float x[3];
-                    shade_phong<float>(nu[p], q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SPEC, L, look, x);
+                    shade_hit<SHADER_PHONG, SPEC>(a, q, sc, tmin[p], nu[p], x);
                     c[p][0] += x[0]; c[p][1] += x[1]; c[p][2] += x[2];
                   }
                 }
@@ -867,7 +947,7 @@ __device__ __forceinline__ void load_grad_rows(const KArgs& a, const Tile& t, in
 // the upstream gradient), pulled from the workgroup's LDS queue.  The next
 // tile's gradient rows are requested before the current tile is processed, so
 // HBM latency hides behind the adjoint.
-template <int P, int SHADER, int SPEC>
+template <int P, int SHADER, int SPEC, int JC, int TR>
 __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   __shared__ WgQueue s_q;
@@ -899,7 +979,8 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
   stage_scene(a, s_scene);          // ends with the workgroup barrier
   int b_cur = -1;
-  float L[3] = {0.f, 0.f, 1.f}, look[3] = {0.f, 0.f, 1.f};
+  SceneP sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
+  float Lv[3] = {0.f, 0.f, 1.f}, lookv[3] = {0.f, 0.f, 1.f};     // VGPR copies of sc.L / sc.look for the hot loop
   // (only when the scene does not fit the LDS accumulators) the last global accumulator
   // flush of a tile is held back into the next iteration: issued at the end of its tile it
   // would sit in front of the next tile's wait for its (older) gradient loads -- the
@@ -947,8 +1028,12 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
       RRT_STAMP(0);
       RRT_STAMP_RT(7);
       if (t.b != b_cur) {
-        cfptr hdr = as_const(a.hdr) + (size_t)t.b * HDR_STRIDE;
-        for (int n = 0; n < 3; ++n) { L[n] = hdr[HDR_LHAT + n]; look[n] = hdr[HDR_LOOK + n]; }
+        load_scene(a, t.b, sc);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          Lv[n] = sc.L[n]; lookv[n] = sc.look[n];
+          asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
+        }
         b_cur = t.b;
       }
       const bool col_ok = lane < t.ncols;
@@ -973,7 +1058,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
         const Tile tn = decode_entry(a, e_nxt, k1, m1, tl1);
         load_grad_rows<P>(a, tn, lane, g);
       }
-      const int col = t.b0 + min(lane, t.ncols - 1);
+      const LaneRay lr = lane_ray<TR>(a, t, lane);
       cuptr mk = as_const(a.mask) + tile * a.nwords;
       RRT_STAMP(1);
 
@@ -983,7 +1068,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
           // several candidates: settle every ray's winner first
           float d[P][3], tmin[P];
           int best[P];
-          gen_rays<P>(a, t, lane, s, d);
+          gen_rays<P, JC, TR>(a, t, lr, s, d);
 #pragma unroll
           for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
           for (int w = 0; w < a.nwords; ++w) {
@@ -1025,18 +1110,38 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
           for (int n = 0; n < ACC_USED; ++n) { acc[n] = 0.f; asm volatile("" : "+v"(acc[n])); }
           bool anyhit = false;
           RRT_STAMP(3);
+          float jcx, jcy;
+          centre_jitter(v, s, jcx, jcy);
+          if (SHADER == SHADER_PHONG && (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC))) {
+            // the hot path: a FAST_* Sphere (rrt_device.h: adjoint_sphere_phong).  Its most used uniforms --
+            // the transform, the light and view directions -- as per-lane VGPR copies: on gfx950 a VALU
+            // instruction with an SGPR source issues at about half the rate of one that reads only VGPRs
+            // (tools/ubench/issue_probe2.hip: v_fmac 2.4 vs 4.3 cycles at two waves per SIMD)
+            float Av[9], ov[3], shm1 = q.sh - 1.0f;
+            load_shape_vgpr(a, s_scene, t.b, k, q, Av, ov);
+            asm volatile("" : "+v"(shm1));
 #pragma unroll 1
-          for (int p = 0; p < t.nrows; ++p) {
-            const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
-            if (on) {
-              int i, j;
-              pixel_to_ray(v, t.a0 + p + v.row0, col, i, j);
-              float sdx, sdy, d[3];
-              sample_dist<float>(v, a.jitter, i, j, s, sdx, sdy);
-              ray_dir<float>(v, i, j, sdx, sdy, d);
-              float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
-              anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
-                                           v.inv_max_depth, L, look, d, up, acc);
+            for (int p = 0; p < t.nrows; ++p) {
+              const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
+              if (on) {
+                float d[3];
+                row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+                const float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
+                anyhit |= adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh,
+                                                            q.powf, Lv, lookv, sc.Llook, d, up, acc);
+              }
+            }
+          } else {
+#pragma unroll 1
+            for (int p = 0; p < t.nrows; ++p) {
+              const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
+              if (on) {
+                float d[3];
+                row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+                const float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
+                anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
+                                             v.inv_max_depth, sc.L, sc.look, d, up, acc);
+              }
             }
           }
           RRT_STAMP(4);
@@ -1370,18 +1475,32 @@ int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStr
   return RRT_OK;
 }
 
+template <int P, int JC, int TR>
+void launch_fwd_jt(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0, 0, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+}
+// JC = 1: jitter at the stratum centre (the per-ray hash / explicit-jitter code drops out of the row
+// loops); TR = view.transpose (which grid coordinate runs along a wave's lanes)
 template <int P>
 void launch_fwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
-  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  const bool jc = a.v.jitter_mode == JITTER_CENTER;
+  if (a.v.transpose) { if (jc) launch_fwd_jt<P, 1, 1>(a, blocks, shader, spec, st); else launch_fwd_jt<P, 0, 1>(a, blocks, shader, spec, st); }
+  else { if (jc) launch_fwd_jt<P, 1, 0>(a, blocks, shader, spec, st); else launch_fwd_jt<P, 0, 0>(a, blocks, shader, spec, st); }
 }
 
+template <int P, int JC, int TR>
+void launch_bwd_jt(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0, 0, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+}
 template <int P>
 void launch_bwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
-  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  const bool jc = a.v.jitter_mode == JITTER_CENTER;
+  if (a.v.transpose) { if (jc) launch_bwd_jt<P, 1, 1>(a, blocks, shader, spec, st); else launch_bwd_jt<P, 0, 1>(a, blocks, shader, spec, st); }
+  else { if (jc) launch_bwd_jt<P, 1, 0>(a, blocks, shader, spec, st); else launch_bwd_jt<P, 0, 0>(a, blocks, shader, spec, st); }
 }
 
 }  // namespace

@@ -30,8 +30,10 @@ def band(n_rows, rank, world_size):
 
 
 def all_reduce_flat(flat, group=None):
-    """Sum the flat parameter-gradient buffer over the ranks, in place."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    """Sum the flat parameter-gradient buffer over the ranks, in place (a no-op
+    without a process group; with one, the collective runs even at world size 1
+    so that a single-GPU rehearsal exercises the same RCCL path)."""
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 

@@ -52,7 +52,19 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
 
 
-def _structs(w2o, material, light, cam, kinds, jitter, opts, flags):
+def _jitter_allows_cull(jitter):
+    """The tile cull bounds a tile's rays assuming sampleDist in [0, 1] (what the reference's
+    (U + sample) / A always is; include/rrt.h).  An explicit jitter tensor outside that range
+    would silently drop hit shapes from tiles, so it is range-checked here (one tiny reduction
+    + sync; explicit jitter is the parity-run mode) and culling is switched off for it.  Inside a
+    HIP-graph capture the check cannot run: cull off."""
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    lo, hi = torch.aminmax(jitter)
+    return bool(lo >= 0.0) and bool(hi <= 1.0)
+
+
+def _structs(w2o, material, light, cam, kinds, jitter, opts, flags, cull=None):
     B = max(w2o.shape[0] if w2o.dim() == 4 else 1,
             material.shape[0] if material.dim() == 3 else 1,
             cam.shape[0] if cam.dim() == 2 else 1)
@@ -73,7 +85,7 @@ def _structs(w2o, material, light, cam, kinds, jitter, opts, flags):
     vw.transpose = int(opts.transpose)
     vw.jitter_mode = opts.jitter_mode
     vw.seed = opts.seed
-    vw.flags = flags | (0 if opts.cull else N.FLAG_NO_CULL)
+    vw.flags = flags | (0 if (opts.cull if cull is None else cull) else N.FLAG_NO_CULL)
     vw.max_depth = opts.max_depth
     vw.cam = _ptr(cam).value
     vw.cam_bstride = 16 if (cam.dim() == 2 and cam.shape[0] > 1) else 0
@@ -139,7 +151,10 @@ class RenderFn(torch.autograd.Function):
             jitter = jitter.detach().contiguous().float()
         _check_inputs(w2o, material, light, cam, kinds, jitter, opts)
         L = N.lib()
-        sc, vw, S, B = _structs(w2o, material, light, cam, kinds, jitter, opts, 0)
+        cull = opts.cull
+        if cull and opts.jitter_mode == N.JITTER_EXPLICIT and not _jitter_allows_cull(jitter):
+            cull = False
+        sc, vw, S, B = _structs(w2o, material, light, cam, kinds, jitter, opts, 0, cull)
         batched = w2o.dim() == 4 or material.dim() == 3 or cam.dim() == 2
         dev = w2o.device
         nbytes = L.rrt_workspace_bytes(ctypes.byref(sc), ctypes.byref(vw))
@@ -152,7 +167,7 @@ class RenderFn(torch.autograd.Function):
             N.check(L.rrt_render_fwd(ctypes.byref(sc), ctypes.byref(vw), _ptr(image), _ptr(ws), nbytes, stream),
                     "rrt_render_fwd")
         ctx.save_for_backward(w2o, material, light, cam)
-        ctx.kinds, ctx.jitter, ctx.opts, ctx.ws, ctx.batched = kinds, jitter, opts, ws, batched
+        ctx.kinds, ctx.jitter, ctx.opts, ctx.ws, ctx.batched, ctx.cull = kinds, jitter, opts, ws, batched, cull
         return image if batched else image[0]
 
     @staticmethod
@@ -162,7 +177,7 @@ class RenderFn(torch.autograd.Function):
         L = N.lib()
         g = grad_image.detach().contiguous().float()
         # the packed scene written by forward is still in ctx.ws
-        sc, vw, S, B = _structs(w2o, material, light, cam, ctx.kinds, ctx.jitter, opts, N.FLAG_REUSE_SETUP)
+        sc, vw, S, B = _structs(w2o, material, light, cam, ctx.kinds, ctx.jitter, opts, N.FLAG_REUSE_SETUP, ctx.cull)
         dev = w2o.device
         flat = torch.empty(w2o.numel() + material.numel() + 6, dtype=torch.float32, device=dev)
         g_w2o = flat[:w2o.numel()].view(w2o.shape)
@@ -202,7 +217,9 @@ def render(w2o, material, light, kinds=None, cam=None, *, x_dims, y_dims, antial
 
     jitter: None or "center" (U = 0.5), an int (hash seed: a reproducible
     stand-in for scene.py:24-25's unseeded draws) or a [y_dims,x_dims,A,2]
-    tensor of sampleDist_x/_y.  ``transpose`` defaults to the root-camera
+    tensor of sampleDist_x/_y (the reference's values (U + sample) / A lie in
+    [0, 1]; a tensor with values outside that range is rendered without the
+    tile cull, whose bounds assume it).  ``transpose`` defaults to the root-camera
     semantics when ``cam`` is None and to the orbit semantics otherwise.
     """
     dev = w2o.device

@@ -59,7 +59,9 @@ class Scene(object):
         (scene.py:24-25); here a hash seed is drawn once per Scene (from
         ``np.random``, like the reference) and reused by every later build(),
         so repeated calls see the same 'baked' jitter.  Pass "center", an int
-        seed, or an explicit [y_dims,x_dims,A,2] sampleDist tensor to control it.
+        seed, or an explicit [y_dims,x_dims,A,2] sampleDist tensor to control it
+        (values in [0, 1] like the reference's (U + sample) / A; anything else is
+        rendered with the tile cull off, see rrt.render).
         ``row0/rows`` render a band of image rows (multi-GPU sharding).
         """
         cam = self.camera

@@ -25,6 +25,7 @@ struct HView {
   int32_t x_dims, y_dims, A, row0, rows, shader, specular, transpose, jitter_mode;
   uint32_t seed;
   float max_depth;
+  int32_t force_generic;   // 1: always shade_phong / adjoint_ray, never the FAST_* code paths
 };
 
 template <class T>
@@ -112,8 +113,18 @@ void fwd(int S, const float* w2o, const float* mat, const float* light, const ui
           c[0] = c[1] = c[2] = shade_depth<T>(h.t, T(v.inv_max_depth));
         } else {
           T colI[3] = {T(p[PS_COLI]), T(p[PS_COLI + 1]), T(p[PS_COLI + 2])};
-          shade_phong<T>(h.nu, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]), as_int(p[PS_POWF]),
-                         v.specular, L, look, c);
+          const int powf = as_int(p[PS_POWF]);
+          // the kernels' dispatch: FAST_* shapes take the lean code path
+          if (!hv.force_generic && adjoint_is_fast(as_int(p[PS_KIND]), powf, v.shader, v.specular)) {
+            if (v.specular)
+              shade_phong_fast<T, 1>(h.nu, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]), powf, L, look,
+                                     T(pk.hdr[HDR_LLOOK]), c);
+            else
+              shade_phong_fast<T, 0>(h.nu, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]), powf, L, look,
+                                     T(pk.hdr[HDR_LLOOK]), c);
+          } else {
+            shade_phong<T>(h.nu, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]), powf, v.specular, L, look, c);
+          }
         }
         for (int q = 0; q < 3; ++q) acc[q] += c[q];
       }
@@ -148,9 +159,19 @@ void bwd(int S, const float* w2o, const float* mat, const float* light, const ui
         T A[9], o[3], colI[3];
         for (int q = 0; q < 9; ++q) A[q] = T(p[PS_A + q]);
         for (int q = 0; q < 3; ++q) { o[q] = T(p[PS_O + q]); colI[q] = T(p[PS_COLI + q]); }
-        adjoint_ray<T>(as_int(p[PS_KIND]), A, o, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]),
-                       T(p[PS_SH]), as_int(p[PS_POWF]), v.shader, v.specular, T(v.inv_max_depth), L, look, d, up,
-                       acc.data() + (size_t)id * ACC_STRIDE);
+        const int kindk = as_int(p[PS_KIND]), powf = as_int(p[PS_POWF]);
+        T* ak = acc.data() + (size_t)id * ACC_STRIDE;
+        if (!hv.force_generic && adjoint_is_fast(kindk, powf, v.shader, v.specular)) {
+          if (v.specular)
+            adjoint_sphere_phong<T, 1>(A, o, colI, T(p[PS_CMAX]), T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]) - T(1),
+                                       T(p[PS_KSSH]), powf, L, look, T(pk.hdr[HDR_LLOOK]), d, up, ak);
+          else
+            adjoint_sphere_phong<T, 0>(A, o, colI, T(p[PS_CMAX]), T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]) - T(1),
+                                       T(p[PS_KSSH]), powf, L, look, T(pk.hdr[HDR_LLOOK]), d, up, ak);
+        } else {
+          adjoint_ray<T>(kindk, A, o, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]), powf, v.shader,
+                         v.specular, T(v.inv_max_depth), L, look, d, up, ak);
+        }
       }
     }
   double gl[6] = {0, 0, 0, 0, 0, 0};

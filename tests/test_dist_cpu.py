@@ -41,7 +41,14 @@ def _worker(rank, world, port, out_dir):
     img, gw, gm, gl = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G[row0:row0 + rows],
                                          x_dims=n, y_dims=n, antialias_samples=2, row0=row0, rows=rows)
     flat = torch.cat([gw.reshape(-1), gm.reshape(-1), gl.reshape(-1)]).float()
-    rdist.all_reduce_flat(flat)                        # the ONE collective of a sharded backward
+    # the ONE collective of a sharded backward, through the hook RenderFn.backward calls on its flat
+    # [g_w2o | g_material | g_light] buffer (rrt/render.py) -- installed by the product's context manager
+    import importlib
+    render_mod = importlib.import_module("rrt.render")
+    assert render_mod._grad_hook[0] is None
+    with rdist.sharded():
+        assert render_mod._grad_hook[0](flat) is flat
+    assert render_mod._grad_hook[0] is None
     full = rdist.gather_image(img.float(), n)
     np.save(os.path.join(out_dir, "flat_%d.npy" % rank), flat.numpy())
     np.save(os.path.join(out_dir, "img_%d.npy" % rank), full.numpy())

@@ -6,9 +6,27 @@ Tolerances (float32 kernel vs float64 oracle), chosen from the float32 noise
 floor of the same formulas measured on the CPU harness (test_device_math.py):
   * image: |d| <= IMG_TOL on every pixel except at most MAX_FLIP_FRAC of them
     (silhouette pixels whose hit/miss flips between float32 and float64);
-  * parameter gradients: max|d| <= GRAD_RTOL * max|g| per tensor (the adjoint
-    divides by sqrt(Delta), which amplifies float32 rounding at grazing rays).
+  * parameter gradients, per tensor: max|d| <= GRAD_TIGHT * max|g| (1e-3, SURVEY
+    section 7).  A check that misses it may still pass on the float32 noise floor
+    of these formulas -- the adjoint divides by sqrt(Delta), which amplifies
+    float32 rounding at grazing rays, and the reference itself rounds its rays to
+    float32 -- measured at the same point by the oracle run in float32:
+    max|d| <= 4 x (float32 oracle's error), and that only up to GRAD_RTOL * max|g|
+    (5e-3; 2e-2 for the thin white-noise band) unless a hit/miss flip is actually
+    present (a pixel of the GPU image off by more than IMG_TOL, or a ray whose
+    winner differs between the float32 and the float64 oracle, ``oracle.hit_ids``);
+  * per entry: every gradient entry, small ones included, within
+    max(ENTRY_RTOL * |entry|, 4 x the float32 oracle's error on that entry,
+    ENTRY_FLOOR * max|g|) -- so an entry above ENTRY_FLOOR/ENTRY_RTOL of the
+    tensor's scale is held to a relative error of its own;
+  * d/dshininess (material column 6) is compared like every other entry, against
+    the oracle's "masked" exponent gradient (the product's documented extension:
+    lanes with a non-positive pow base contribute 0; include/rrt.h).
+Every check appends (test, tensor, error / scale, flips) to the report printed at
+the end of the module (and to $RRT_PARITY_REPORT when set).
 """
+import json
+import os
 import numpy as np
 import pytest
 import torch
@@ -19,7 +37,30 @@ pytestmark = pytest.mark.gpu
 
 IMG_TOL = 2e-4
 MAX_FLIP_FRAC = 5e-4
+GRAD_TIGHT = 1e-3
 GRAD_RTOL = 5e-3
+ENTRY_RTOL = 5e-3
+ENTRY_FLOOR = 2e-5
+
+_REPORT = []
+
+
+def _note(what, rel, flips, fallback):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    _REPORT.append({"test": test, "tensor": what, "rel_err": rel, "flips": flips, "fallback": fallback})
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _parity_report():
+    yield
+    if _REPORT:
+        worst = max(_REPORT, key=lambda r: r["rel_err"])
+        print("\nparity report: %d gradient checks, %d needed the float32-floor clause; worst %s" % (
+            len(_REPORT), sum(r["fallback"] for r in _REPORT), json.dumps(worst)))
+        path = os.environ.get("RRT_PARITY_REPORT")
+        if path:
+            with open(path, "w") as f:
+                json.dump(_REPORT, f, indent=1)
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +91,7 @@ def hip_render(dev, w2o, mat, light, kinds, grad=None, **kw):
 
 
 def oracle(w2o, mat, light, kinds, grad, *, x_dims, y_dims, antialias_samples, jitter=None, cam=None,
-           shader="phong", specular=True, max_depth=1.0, row0=0, rows=None):
+           shader="phong", specular=True, max_depth=1.0, row0=0, rows=None, dtype=torch.float64, want_flips=False):
     sd = None
     if isinstance(jitter, (int, np.integer)):
         sd = O.sample_dist_from_uniform(O.hash_u01(jitter, y_dims, x_dims, antialias_samples))
@@ -60,11 +101,15 @@ def oracle(w2o, mat, light, kinds, grad, *, x_dims, y_dims, antialias_samples, j
     if cam is not None:
         cam_o2w = np.eye(4)
         cam_o2w[:3, :4] = np.asarray(cam[:12]).reshape(3, 4)
-    img, gw, gm, gl = O.render_and_grads(
-        w2o, mat, light, list(kinds) if kinds is not None else None, grad_image=grad,
-        x_dims=x_dims, y_dims=y_dims, antialias_samples=antialias_samples, shader=shader, specular=specular,
-        max_depth=max_depth, cam_o2w=cam_o2w, sample_dist=sd, row0=row0, rows=rows)
-    return img.numpy(), gw.numpy(), gm.numpy(), gl.numpy()
+    kw = dict(x_dims=x_dims, y_dims=y_dims, antialias_samples=antialias_samples, shader=shader, specular=specular,
+              max_depth=max_depth, cam_o2w=cam_o2w, sample_dist=sd, row0=row0, rows=rows, shininess_grad="masked")
+    kl = list(kinds) if kinds is not None else None
+    img, gw, gm, gl = O.render_and_grads(w2o, mat, light, kl, grad_image=grad, dtype=dtype, **kw)
+    if want_flips:
+        hk = {k: kw[k] for k in ("x_dims", "y_dims", "antialias_samples", "cam_o2w", "sample_dist", "row0", "rows")}
+        ids = [O.hit_ids(w2o, kl, dtype=dt, **hk) for dt in (torch.float32, torch.float64)]
+        return int((ids[0] != ids[1]).sum())
+    return img.double().numpy(), gw.double().numpy(), gm.double().numpy(), gl.double().numpy()
 
 
 def assert_image_close(a, b, what=""):
@@ -75,10 +120,51 @@ def assert_image_close(a, b, what=""):
 
 
 def assert_grad_close(a, b, what="", rtol=None):
+    """plain max-norm check (structural tests: two GPU runs against each other, sums over a batch)"""
     rtol = GRAD_RTOL if rtol is None else rtol
     scale = max(np.abs(b).max(), 1e-20)
     err = np.abs(a - b).max()
     assert err <= rtol * scale, "%s: max|d|=%g vs scale %g (rel %g)" % (what, err, scale, err / scale)
+
+
+def assert_grads_vs_oracle(got, ref, f32, image_flips, count_flips, loose=None):
+    """got / ref / f32: (g_w2o, g_material[S,7], g_light) of the GPU, the float64 oracle and the
+    float32 oracle (lazily: `f32` and `count_flips` are callables, only evaluated when the tight
+    bound fails).  See the module docstring for the bounds."""
+    cache = {}
+
+    def floor():
+        if "f32" not in cache:
+            cache["f32"] = f32()
+        return cache["f32"]
+
+    def flips():
+        if "flips" not in cache:
+            cache["flips"] = image_flips + count_flips()
+        return cache["flips"]
+    for idx, what in enumerate(("g_w2o", "g_material", "g_light")):
+        a, b = np.asarray(got[idx]), np.asarray(ref[idx])
+        assert np.isfinite(a).all(), what
+        if b.size == 0:
+            continue
+        scale = max(np.abs(b).max(), 1e-20)
+        err = np.abs(a - b)
+        tol, fallback = GRAD_TIGHT * scale, False
+        if err.max() > tol:
+            fl = 4.0 * np.abs(np.asarray(floor()[idx]) - b).max()
+            cap = (loose or GRAD_RTOL) * scale
+            tol, fallback = max(tol, fl if flips() > 0 else min(fl, cap)), True
+        _note(what, float(err.max() / scale), cache.get("flips", image_flips), fallback)
+        assert err.max() <= tol, "%s: max|d|=%g vs scale %g (rel %.2e), flips %d" % (what, err.max(), scale, err.max() / scale,
+                                                                                    flips())
+        # per entry (small entries too)
+        ent = np.maximum(ENTRY_RTOL * np.abs(b), ENTRY_FLOOR * scale)
+        if (err > ent).any():
+            fl = np.abs(np.asarray(floor()[idx]) - b)
+            ent = np.maximum(ent, 4.0 * fl)
+        worst = np.unravel_index(np.argmax(err - ent), err.shape)
+        assert (err <= ent).all(), "%s%s: |d|=%g, entry %g, allowed %g (scale %g)" % (what, list(worst), err[worst], b[worst],
+                                                                                    ent[worst], scale)
 
 
 def check_scene(dev, w2o, mat, light, kinds, seed=0, grad_rtol=None, **kw):
@@ -91,10 +177,10 @@ def check_scene(dev, w2o, mat, light, kinds, seed=0, grad_rtol=None, **kw):
     hi, hw, hm, hl = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
     oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **okw)
     assert_image_close(hi, oi, "image")
-    assert_grad_close(hw, ow, "g_w2o", grad_rtol)
-    assert_grad_close(hm[:, :6], om[:, :6], "g_material", grad_rtol)
-    assert_grad_close(hl, ol, "g_light", grad_rtol)
-    assert np.isfinite(hm).all()
+    image_flips = int((np.abs(hi - oi).max(-1) > IMG_TOL).sum())
+    assert_grads_vs_oracle((hw, hm, hl), (ow, om, ol),
+                           lambda: oracle(w2o, mat, light, kinds, G, dtype=torch.float32, **okw)[1:],
+                           image_flips, lambda: oracle(w2o, mat, light, kinds, G, want_flips=True, **okw), loose=grad_rtol)
     return hi
 
 
@@ -177,6 +263,17 @@ def test_explicit_jitter(dev):
     n, A = 96, 3
     U = np.random.RandomState(4).rand(n, n, A, 2).astype(np.float32)
     sd = O.sample_dist_from_uniform(U)
+    check_scene(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=A, jitter=sd)
+
+
+def test_explicit_jitter_outside_unit_range(dev):
+    """sampleDist outside [0, 1] (not something the reference produces): the tile cull's bounds do
+    not cover it, so rrt.render switches the cull off for such a tensor -- results still match the
+    oracle, including shapes that only the far-displaced rays reach"""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.random_spheres(6, seed=4)
+    n, A = 80, 2
+    sd = (np.random.RandomState(7).rand(n, n, A, 2) * 24.0 - 12.0).astype(np.float32)    # up to 12 pixels either way
     check_scene(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=A, jitter=sd)
 
 
@@ -387,7 +484,7 @@ def test_batch_beyond_lds_staging(dev):
     for b in range(B):
         gm += oracle(w[b], mat, light, kinds, G[b], x_dims=n, y_dims=n, antialias_samples=4, specular=False,
                      jitter=4, cam=cams[b])[2]
-    assert_grad_close(tm.grad.cpu().double().numpy()[:, :6], gm[:, :6], "g_material summed over the batch")
+    assert_grad_close(tm.grad.cpu().double().numpy(), gm, "g_material summed over the batch (d/dshininess included)")
 
 
 def test_backward_twice_and_forward_only_reuse(dev):
@@ -516,63 +613,6 @@ def test_backward_with_and_without_saved_queues(dev, monkeypatch):
         assert_grad_close(x, y, what, rtol=1e-4)
 
 
-def test_gradient_descent_loss_curve_matches_oracle(dev):
-    """the match_mirror.py loop (match_mirror.py:36-53) with GDOptimizer's update
-    rule (optimize.py:19-27), free-running on the GPU for 25 steps.  At every step the float64
-    oracle, evaluated at the GPU's current parameters, must give the same loss and image, and
-    the same gradient up to the float32 noise floor of these formulas -- measured, at the same
-    point, by the oracle itself run in float32 (a grazing ray makes dLoss/dcentre jump by
-    O(|g|) for a 1e-7 change of the centre; the free-running float64 trajectory therefore
-    separates from any float32 one at the first such event, here around step 21)."""
-    import rrt
-    from rrt import synthetic
-    w2o0, mat, light, kinds = synthetic.match_mirror(with_square=True)
-    n, lr, mom = 96, 8e-6, 0.1
-    kw = dict(x_dims=n, y_dims=n, antialias_samples=1, jitter="center")
-    okw = dict(x_dims=n, y_dims=n, antialias_samples=1)
-
-    def w2o_of(centres):
-        # Sphere(translate(c)): w2o = translate(c)^-1 -> last column -c (transform.py:60-70)
-        w = torch.tensor(w2o0, dtype=centres.dtype, device=centres.device)
-        col = torch.cat([-centres, w[2:, :, 3]], 0)              # the Square keeps its own transform
-        return torch.cat([w[:, :, :3], col[:, :, None]], 2)
-
-    def oracle_at(c32, target, dtype):
-        co = c32.to(dtype).requires_grad_(True)
-        img = O.render(w2o_of(co), torch.tensor(mat, dtype=dtype), torch.tensor(light, dtype=dtype), list(kinds),
-                       dtype=dtype, **okw)
-        loss = ((img - target.to(dtype)) ** 2).sum()
-        (g,) = torch.autograd.grad(loss, co)
-        return img.detach().double(), loss.item(), g.double()
-
-    c = torch.tensor([[-.5, -.5, 4.], [.5, .5, 4.]], device=dev, requires_grad=True)
-    tm, tl = torch.tensor(mat, device=dev), torch.tensor(light, device=dev)
-    target = torch.flip(rrt.render(w2o_of(c.detach()), tm, tl, kinds, **kw), dims=[1])     # np.fliplr
-    target_cpu = target.cpu()
-    vel = torch.zeros_like(c)
-    losses, worst = [], 0.0
-    for _ in range(25):
-        img = rrt.render(w2o_of(c), tm, tl, kinds, **kw)
-        loss = ((img - target) ** 2).sum()
-        (g,) = torch.autograd.grad(loss, c)
-        c_cpu = c.detach().cpu()
-        img64, loss64, g64 = oracle_at(c_cpu, target_cpu, torch.float64)
-        _, _, g32 = oracle_at(c_cpu, target_cpu, torch.float32)
-        assert_image_close(img.detach().cpu().double().numpy(), img64.numpy(), "image")
-        assert abs(loss.item() - loss64) <= 1e-5 * loss64
-        scale = g64.abs().max().item()
-        err = (g.cpu().double() - g64).abs().max().item()
-        floor = (g32 - g64).abs().max().item()
-        assert err <= max(GRAD_RTOL * scale, 4.0 * floor), (err, scale, floor)
-        worst = max(worst, err / scale)
-        losses.append(loss.item())
-        with torch.no_grad():
-            vel = mom * vel - lr * g
-            c += vel
-    assert losses[-1] < 0.93 * losses[0]
-    assert (c.detach().cpu() - torch.tensor([[-.5, -.5, 4.], [.5, .5, 4.]])).abs().max() > 0.05
-
-
 def _random_scene(rs):
     """shapes with general affine world->object maps (rotation about a random axis, anisotropic
     scale, translation), a few of them Squares; random materials and light"""
@@ -618,21 +658,10 @@ def test_random_scenes_vs_oracle(dev, seed):
     hi, hw, hm, hl = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
     oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **kw)
     assert_image_close(hi, oi, "image")
-    # float32 noise floor of the same formulas
-    sd = O.sample_dist_from_uniform(O.hash_u01(kw["jitter"], y, x, A))
-    cam_o2w = None
-    if "cam" in kw:
-        cam_o2w = np.eye(4); cam_o2w[:3, :4] = np.asarray(kw["cam"][:12]).reshape(3, 4)
-    _, fw, fm, fl = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=x, y_dims=y, antialias_samples=A,
-                                       shader=shader, specular=kw["specular"], max_depth=12.0, cam_o2w=cam_o2w,
-                                       sample_dist=sd, dtype=torch.float32)
-    for got, ref, f32, what in ((hw, ow, fw.double().numpy(), "g_w2o"), (hm[:, :6], om[:, :6], fm.double().numpy()[:, :6],
-                                "g_material"), (hl, ol, fl.double().numpy(), "g_light")):
-        scale = max(np.abs(ref).max(), 1e-20)
-        err = np.abs(got - ref).max()
-        floor = np.abs(f32 - ref).max()
-        assert err <= max(GRAD_RTOL * scale, 4.0 * floor), "%s: err %g scale %g float32 floor %g" % (what, err, scale, floor)
-    assert np.isfinite(hm).all()
+    image_flips = int((np.abs(hi - oi).max(-1) > IMG_TOL).sum())
+    assert_grads_vs_oracle((hw, hm, hl), (ow, om, ol),
+                           lambda: oracle(w2o, mat, light, kinds, G, dtype=torch.float32, **kw)[1:],
+                           image_flips, lambda: oracle(w2o, mat, light, kinds, G, want_flips=True, **kw))
 
 
 def synthetic_orbit_cam(y):
