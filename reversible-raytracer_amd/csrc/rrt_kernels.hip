@@ -931,14 +931,31 @@ __device__ __forceinline__ void wave_sums_22(const float acc[ACC_USED], float r6
   }
 }
 
+// The upstream-gradient rows of a tile go straight from HBM into the wave's LDS staging buffer, one
+// tile ahead of their use (LDS-DMA: no VGPRs, no ds_write).  A tile row is ncols * 12 contiguous
+// bytes: lanes 0..n16-1 move 16 bytes each (global_load_lds_dwordx4 lands lane l's bytes at LDS
+// offset 16 l, so the row arrives compact, pixel-major [pixel][3]) and, on ragged tiles only, up to
+// three lanes move the remaining dwords one by one -- no byte beyond the row is touched.  Pixel l
+// reads words 3l..3l+2: conflict-free, 3 is odd.  Rows outside the image are not loaded (their slots
+// keep stale bytes; the row loops never read them).  The compiler does not track the asynchronous
+// LDS write: the consumer waits with s_waitcnt vmcnt(0).
+// (global_load_lds_dwordx3 pads every lane to 16 bytes in LDS -- measured -- which would make the
+// double buffer 128 KB.)
+constexpr int UP_ROW = 64 * 3;
 template <int P>
-__device__ __forceinline__ void load_grad_rows(const KArgs& a, const Tile& t, int lane, F3 g[P]) {
+__device__ __forceinline__ void prefetch_grad_rows(const KArgs& a, const Tile& t, int lane, float* dst) {
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  const int nd = t.ncols * 3, n16 = nd >> 2, tail = nd & 3;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    g[p].x = g[p].y = g[p].z = 0.f;
-    if (lane < t.ncols && p < t.nrows) {
-      const F3* in = reinterpret_cast<const F3*>(a.grad + (((size_t)t.b * a.v.rows + t.a0 + p) * a.v.ncols + t.b0) * 3);
-      g[p] = in[lane];
+    if (p < t.nrows) {
+      const float* row = a.grad + (((size_t)t.b * a.v.rows + t.a0 + p) * a.v.ncols + t.b0) * 3;
+      if (lane < n16) __builtin_amdgcn_global_load_lds((gptr)(row + 4 * lane), (lptr)(dst + p * UP_ROW), 16, 0, 0);
+      if (tail) {
+        if (lane < tail)
+          __builtin_amdgcn_global_load_lds((gptr)(row + 4 * n16 + lane), (lptr)(dst + p * UP_ROW + 4 * n16), 4, 0, 0);
+      }
     }
   }
 }
@@ -951,9 +968,13 @@ template <int P, int SHADER, int SPEC, int JC, int TR>
 __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   __shared__ WgQueue s_q;
-  // wave-private staging: upstream gradient (3) and winner id (1) per (row, lane)
-  __shared__ float s_up[WAVES][P][3][64];
-  __shared__ int s_best[WAVES][P][64];
+  // wave-private staging: the upstream gradient rows of the current and of the next tile (LDS-DMA
+  // double buffer), and the winner id per (row, lane).  The winners live in the queue's scan tables,
+  // which are dead once a batch has been dealt (152 KB of the CU's 160 KB at P = 4).
+  __shared__ float s_up[WAVES][2][P][UP_ROW];
+  static_assert(sizeof(s_q.ex) + sizeof(s_q.cnt01) >= sizeof(int) * WAVES * P * 64 &&
+                offsetof(WgQueue, cnt01) == offsetof(WgQueue, ex) + sizeof(s_q.ex), "s_best aliases ex + cnt01");
+  int (*s_best)[P][64] = reinterpret_cast<int (*)[P][64]>(&s_q.ex[0][0]);
   // workgroup-level gradient accumulators: a wave's 22 sums go to LDS (ds_add_f32) and the
   // workgroup adds each touched row to HBM once, at the end.  A same-address global atomic
   // costs ~12 ns and every tile of a shape adds to the same 22 words: one big sphere
@@ -980,7 +1001,6 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   stage_scene(a, s_scene);          // ends with the workgroup barrier
   int b_cur = -1;
   SceneP sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
-  float Lv[3] = {0.f, 0.f, 1.f}, lookv[3] = {0.f, 0.f, 1.f};     // VGPR copies of sc.L / sc.look for the hot loop
   // (only when the scene does not fit the LDS accumulators) the last global accumulator
   // flush of a tile is held back into the next iteration: issued at the end of its tile it
   // would sit in front of the next tile's wait for its (older) gradient loads -- the
@@ -1016,11 +1036,11 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     }
     unsigned long long e_cur = 0, e_nxt = 0;
     bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
-    F3 g[P];
+    int buf = 0;
     if (has_cur) {
       int k0; bool multi; long long tile;
       const Tile t = decode_entry(a, e_cur, k0, multi, tile);
-      load_grad_rows<P>(a, t, lane, g);
+      prefetch_grad_rows<P>(a, t, lane, &s_up[wave][0][0][0]);
     }
     while (has_cur) {
       int k0; bool multi; long long tile;
@@ -1029,21 +1049,13 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
       RRT_STAMP_RT(7);
       if (t.b != b_cur) {
         load_scene(a, t.b, sc);
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-          Lv[n] = sc.L[n]; lookv[n] = sc.look[n];
-          asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
-        }
         b_cur = t.b;
       }
       const bool col_ok = lane < t.ncols;
-      // (1) this tile's gradient rows, requested one tile ago
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        s_up[wave][p][0][lane] = g[p].x * v.inv_A;
-        s_up[wave][p][1][lane] = g[p].y * v.inv_A;
-        s_up[wave][p][2][lane] = g[p].z * v.inv_A;
-      }
+      // (1) this tile's gradient rows, requested one tile ago, have landed in s_up[wave][buf] once the wave's
+      // vector-memory counter is at zero (nothing younger is outstanding at this point)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float* up_rows = &s_up[wave][buf][0][0];
       // (2) the accumulator atomic held back from the previous tile
       if (held) {
         if (lane < ACC_USED)
@@ -1056,15 +1068,19 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
       if (has_nxt) {
         int k1; bool m1; long long tl1;
         const Tile tn = decode_entry(a, e_nxt, k1, m1, tl1);
-        load_grad_rows<P>(a, tn, lane, g);
+        prefetch_grad_rows<P>(a, tn, lane, &s_up[wave][buf ^ 1][0][0]);
       }
       const LaneRay lr = lane_ray<TR>(a, t, lane);
       cuptr mk = as_const(a.mask) + tile * a.nwords;
       RRT_STAMP(1);
 
+      // several candidates: per sample, settle every ray's winner, then run the adjoint per winning shape.
+      // One candidate: the samples run INSIDE the accumulation, so the tile pays one butterfly, not one per sample.
 #pragma unroll 1
-      for (int s = 0; s < v.A; ++s) {
+      for (int s0 = 0; s0 < (multi ? v.A : 1); ++s0) {
+        const int s_lo = multi ? s0 : 0, s_hi = multi ? s0 + 1 : v.A;
         if (multi) {
+          const int s = s0;
           // several candidates: settle every ray's winner first
           float d[P][3], tmin[P];
           int best[P];
@@ -1110,37 +1126,52 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
           for (int n = 0; n < ACC_USED; ++n) { acc[n] = 0.f; asm volatile("" : "+v"(acc[n])); }
           bool anyhit = false;
           RRT_STAMP(3);
-          float jcx, jcy;
-          centre_jitter(v, s, jcx, jcy);
           if (SHADER == SHADER_PHONG && (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC))) {
             // the hot path: a FAST_* Sphere (rrt_device.h: adjoint_sphere_phong).  Its most used uniforms --
             // the transform, the light and view directions -- as per-lane VGPR copies: on gfx950 a VALU
             // instruction with an SGPR source issues at about half the rate of one that reads only VGPRs
             // (tools/ubench/issue_probe2.hip: v_fmac 2.4 vs 4.3 cycles at two waves per SIMD)
-            float Av[9], ov[3], shm1 = q.sh - 1.0f;
+            float Av[9], ov[3], Lv[3], lookv[3], shm1 = q.sh - 1.0f;
             load_shape_vgpr(a, s_scene, t.b, k, q, Av, ov);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+              Lv[n] = sc.L[n]; lookv[n] = sc.look[n];
+              asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
+            }
             asm volatile("" : "+v"(shm1));
 #pragma unroll 1
-            for (int p = 0; p < t.nrows; ++p) {
-              const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
-              if (on) {
-                float d[3];
-                row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
-                const float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
-                anyhit |= adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh,
-                                                            q.powf, Lv, lookv, sc.Llook, d, up, acc);
+            for (int s = s_lo; s < s_hi; ++s) {
+              float jcx, jcy;
+              centre_jitter(v, s, jcx, jcy);
+#pragma unroll 1
+              for (int p = 0; p < t.nrows; ++p) {
+                const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
+                if (on) {
+                  float d[3];
+                  row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+                  const float* ur = up_rows + p * UP_ROW + 3 * lane;
+                  const float up[3] = {ur[0], ur[1], ur[2]};
+                  anyhit |= adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh,
+                                                              q.powf, Lv, lookv, sc.Llook, d, up, acc);
+                }
               }
             }
           } else {
 #pragma unroll 1
-            for (int p = 0; p < t.nrows; ++p) {
-              const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
-              if (on) {
-                float d[3];
-                row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
-                const float up[3] = {s_up[wave][p][0][lane], s_up[wave][p][1][lane], s_up[wave][p][2][lane]};
-                anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
-                                             v.inv_max_depth, sc.L, sc.look, d, up, acc);
+            for (int s = s_lo; s < s_hi; ++s) {
+              float jcx, jcy;
+              centre_jitter(v, s, jcx, jcy);
+#pragma unroll 1
+              for (int p = 0; p < t.nrows; ++p) {
+                const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
+                if (on) {
+                  float d[3];
+                  row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+                  const float* ur = up_rows + p * UP_ROW + 3 * lane;
+                  const float up[3] = {ur[0], ur[1], ur[2]};
+                  anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
+                                               v.inv_max_depth, sc.L, sc.look, d, up, acc);
+                }
               }
             }
           }
@@ -1152,6 +1183,10 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
           // and finish with four DPP adds -- 59 VALU ops instead of 22 full wave sums (176)
           float r6[6];
           wave_sums_22(acc, r6);
+          // every accumulator is linear in the upstream gradient: the 1/antialias_samples of the
+          // sample average (scene.py:50) is applied to the six sums instead of to every gradient row
+#pragma unroll
+          for (int m = 0; m < 6; ++m) r6[m] *= v.inv_A;
           if (a.lds_scene) {
             // row j of r6[m] holds total m + {0,6,11,17}[j] in its last lane (r6[5]: rows 0 and 2 only)
             float* row = &s_acc[((size_t)t.b * a.S + k) * ACC_STRIDE + (lane >> 4) * 6 - (lane >> 5)];
@@ -1181,6 +1216,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
       RRT_STAMP_RT(2);     // overwrites the phase-1 stamp: real time at the end of the tile
       e_cur = e_nxt;
       has_cur = has_nxt;
+      buf ^= 1;
     }
   }
   if (held && lane < ACC_USED)
