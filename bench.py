@@ -163,25 +163,38 @@ class Job(object):
 
 
 def cpu_baseline(size, spheres, aa, rows):
-    """The CPU oracle (a float32 op-for-op restatement of the reference's
-    Theano graph + autograd) on a band of `rows` rows of the same workload."""
+    """The CPU oracle (a float32 op-for-op restatement of the reference's Theano graph + autograd,
+    array-at-a-time like the Theano graph) on a band of the same workload, timed on this host:
+    once on the GPU box's core share (16 threads) and once on ONE thread (Theano's elementwise
+    loops are single-threaded without OpenMP, README.md:11) on a band an eighth as high.  The
+    Mrays/s of a band is what the 4096-row image would run at (every row costs the same: the
+    oracle shades every shape at every pixel); it is an extrapolation, and says so."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import rrt_oracle as O
     from rrt import synthetic
     w2o, mat, light, kinds = synthetic.random_spheres(spheres, seed=0)
-    row0 = max(0, size // 2 - rows // 2)
-    rows = min(rows, size - row0)
-    G = np.random.RandomState(0).randn(rows, size, 3).astype(np.float32)
+
+    def run(rows, threads):
+        row0 = max(0, size // 2 - rows // 2)
+        rows = min(rows, size - row0)
+        G = np.random.RandomState(0).randn(rows, size, 3).astype(np.float32)
+        torch.set_num_threads(threads)
+        t0 = time.time()
+        O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=size, y_dims=size,
+                           antialias_samples=aa, row0=row0, rows=rows, dtype=torch.float32)
+        dt = time.time() - t0
+        return rows * size * aa / dt / 1e6, row0, rows, dt
     # the GPU box gives one GPU a 16-core share; torch's default (all 128 logical CPUs) only adds overhead
     threads = min(16, os.cpu_count() or 1)
+    v_all, r0, nr, dt_all = run(rows, threads)
+    v_one, r1, n1, dt_one = run(max(16, rows // 8), 1)
     torch.set_num_threads(threads)
-    t0 = time.time()
-    O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=size, y_dims=size,
-                       antialias_samples=aa, row0=row0, rows=rows, dtype=torch.float32)
-    dt = time.time() - t0
-    return {"value": rows * size * aa / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "rows [%d,%d) of the %dx%d/%d-sphere workload, fwd+bwd, float32 torch-CPU oracle, %.1f s"
-                      % (row0, row0 + rows, size, size, spheres, dt)}
+    return {"value": v_all, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "rows [%d,%d) of the %dx%d/%d-sphere workload, fwd+bwd, float32 torch-CPU oracle, %.1f s; the figure "
+                      "for the whole %d-row image is this band's rate (extrapolation: every row costs the same)"
+                      % (r0, r0 + nr, size, size, spheres, dt_all, size),
+            "one_thread": {"value": v_one, "unit": "Mrays/s", "cores": 1,
+                           "sample": "rows [%d,%d), %.1f s (same extrapolation)" % (r1, r1 + n1, dt_one)}}
 
 
 def parity_sample(dev, size, spheres, aa, rows=48):
@@ -310,26 +323,44 @@ def main():
                    "k_fwd_GBs": px * BYTES_PER_PIXEL_FWD / t_f / 1e9,
                    "k_bwd_GBs": px * BYTES_PER_PIXEL_BWD / t_b / 1e9,
                    "fwd_plus_bwd_GBs": px * (BYTES_PER_PIXEL_FWD + BYTES_PER_PIXEL_BWD) / (t_f + t_b) / 1e9}
-        dom_fwd = t_f >= t_b
-        ach = kernels["k_fwd_GBs"] if dom_fwd else kernels["k_bwd_GBs"]
-        # HBM bytes per launch from the committed PMC passes (same workload only)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            tj = json.load(open(tpath))
-            w = tj["workload"]
-            if (w["size"], w["spheres"], w["aa"]) == (args.size, args.spheres, args.aa):
-                k = tj["k_fwd"] if dom_fwd else tj["k_bwd"]
-                traffic = (k["write_bytes"] + k["fetch_bytes_raw"]) if dom_fwd else (k["fetch_bytes_x2"] + k["write_bytes"])
-        roofline = {"bound": "hbm", "kernel": "k_fwd" if dom_fwd else "k_bwd", "achieved": ach,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "note": None if dom_fwd else "k_bwd skips the gradient of tiles no shape can hit and is bound by "
-                                                 "FP32 VALU issue at this coverage, not by HBM (DESIGN.md section 6)"}
+        # counters of the same command (rocprofv3 --pmc, tools/profile_round.sh -> profiles/): HBM bytes and VALU
+        # wave-instructions per launch; VALU issue peak from tools/ubench/issue_probe2.hip
+        prof = None
+        ppath = os.path.join(REPO, "profiles", "r02_counters.json")
+        if os.path.exists(ppath) and world == 1:
+            pj = json.load(open(ppath))
+            pw = pj["workload"]
+            if (pw["size"], pw["spheres"], pw["aa"]) == (args.size, args.spheres, args.aa):
+                prof = pj
 
-        # the other render kernel, same definition (k_fwd is the HBM-bound one: pure image writes)
-        other = "k_bwd" if dom_fwd else "k_fwd"
-        roofline_other = {"bound": "hbm", "kernel": other, "achieved": kernels[other + "_GBs"], "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": kernels[other + "_GBs"] / HBM_PEAK_GBS}
+        def roof(name, t, alg_bytes):
+            """both rooflines of one kernel; `bound` = the wall it is nearer to (by real traffic when known)"""
+            hbm_alg = alg_bytes / t / 1e9
+            r = {"kernel": name, "us": t * 1e6, "achieved_hbm_fraction": hbm_alg / HBM_PEAK_GBS,
+                 "algorithmic_GBs": hbm_alg, "achieved_valu_fraction": None, "traffic": None, "traffic_source": None}
+            hbm_real = hbm_alg
+            if prof is not None:
+                k = prof[name]
+                r["traffic"] = k["hbm_bytes"]
+                r["traffic_source"] = "from_profile: profiles/r02_counters.json (%s)" % prof["source"]
+                hbm_real = k["hbm_bytes"] / t / 1e9
+                peak = prof["valu_peak_inst_per_cycle_per_simd"] * prof["simds"] * prof["clock_ghz"]      # Ginst/s
+                r["valu_Ginst_s"] = k["valu_insts"] / t / 1e9
+                r["valu_peak_Ginst_s"] = peak
+                r["achieved_valu_fraction"] = r["valu_Ginst_s"] / peak
+            vf = r["achieved_valu_fraction"] or 0.0
+            if vf > hbm_real / HBM_PEAK_GBS:
+                r.update({"bound": "valu", "achieved": r["valu_Ginst_s"], "peak": r["valu_peak_Ginst_s"],
+                          "unit": "Ginst/s (wave64 VALU instructions)", "frac": vf})
+            else:
+                r.update({"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": hbm_alg / HBM_PEAK_GBS})
+            return r
+        r_f = roof("k_fwd", t_f, px * BYTES_PER_PIXEL_FWD)
+        r_b = roof("k_bwd", t_b, px * BYTES_PER_PIXEL_BWD)
+        roofline, roofline_other = (r_f, r_b) if t_f >= t_b else (r_b, r_f)
+        kernels["step_algorithmic_GBs"] = px * (BYTES_PER_PIXEL_FWD + BYTES_PER_PIXEL_BWD) / (elapsed / args.steps) / 1e9
+        kernels["step_hbm_fraction"] = kernels["step_algorithmic_GBs"] / HBM_PEAK_GBS
     else:
         roofline_other = None
 

@@ -95,6 +95,12 @@ template <class T> RRT_HD T m_rsqrt(T x) { return T(1) / sqrt(x); }
 template <class T> RRT_HD T m_log2(T x) { return log2(x); }
 template <class T> RRT_HD T m_exp2(T x) { return exp2(x); }
 template <class T> RRT_HD T m_abs(T x) { return x < T(0) ? -x : x; }
+// a*b + c with ONE rounding, spelled out wherever the forward image depends on it: left to the compiler,
+// which product of "x*y + z*w" gets fused depends on where the operands live (SGPR or VGPR), and the
+// same pixel would differ in its last bit between the single- and the multi-candidate code path
+RRT_HD float m_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RRT_HD double m_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <class T> RRT_HD T dot3(const T a[3], const T b[3]) { return m_fma(a[2], b[2], m_fma(a[1], b[1], a[0] * b[0])); }
 template <class T> RRT_HD T m_inf() { return T(INFINITY); }
 template <class T> RRT_HD T m_nan() { return T(NAN); }
 
@@ -189,15 +195,15 @@ RRT_HD void sample_dist(const ViewT<T>& v, const float* jitter, int i, int j, in
 // jx, jy = sampleDist / dims.  Every caller (kernels, CPU harness) goes through ray_dir_parts,
 // so a ray has the same bits whichever kernel, tile shape or row band generates it.
 template <class T>
-RRT_HD T grid_u(const ViewT<T>& v, int i) { return T(0.5) + T(i) * T(v.ustep); }
+RRT_HD T grid_u(const ViewT<T>& v, int i) { return m_fma(T(i), T(v.ustep), T(0.5)); }
 template <class T>
-RRT_HD T grid_w(const ViewT<T>& v, int j) { return T(-0.5) + T(j) * T(v.vstep); }
+RRT_HD T grid_w(const ViewT<T>& v, int j) { return m_fma(T(j), T(v.vstep), T(-0.5)); }
 
 template <class T>
 RRT_HD void ray_dir_parts(T u, T w, T q, T cr, T jx, T jy, T d[3]) {
-  T inv = m_rsqrt<T>(cr * cr + q);
-  d[0] = u * inv + jx;
-  d[1] = w * inv + jy;
+  T inv = m_rsqrt<T>(m_fma(cr, cr, q));
+  d[0] = m_fma(u, inv, jx);
+  d[1] = m_fma(w, inv, jy);
   d[2] = inv;
 }
 
@@ -205,7 +211,7 @@ template <class T>
 RRT_HD void ray_dir(const ViewT<T>& v, int i, int j, T sdx, T sdy, T d[3]) {
   T u = grid_u<T>(v, i), w = grid_w<T>(v, j);
   T cl = v.transpose ? u : w, cr = v.transpose ? w : u;
-  ray_dir_parts<T>(u, w, cl * cl + T(1), cr, sdx * T(v.inv_xd), sdy * T(v.inv_yd), d);
+  ray_dir_parts<T>(u, w, m_fma(cl, cl, T(1)), cr, sdx * T(v.inv_xd), sdy * T(v.inv_yd), d);
 }
 
 // Output pixel (a,b) of the image window -> ray grid index (i,j).
@@ -218,9 +224,9 @@ RRT_HD void pixel_to_ray(const ViewT<T>& v, int a, int b, int& i, int& j) {
 // Object-space ray direction r' = A' d.
 template <class T>
 RRT_HD void xform_dir(const T* A, const T d[3], T r[3]) {
-  r[0] = A[0] * d[0] + A[1] * d[1] + A[2] * d[2];
-  r[1] = A[3] * d[0] + A[4] * d[1] + A[5] * d[2];
-  r[2] = A[6] * d[0] + A[7] * d[1] + A[8] * d[2];
+  r[0] = dot3<T>(A, d);
+  r[1] = dot3<T>(A + 3, d);
+  r[2] = dot3<T>(A + 6, d);
 }
 
 // Sphere.distance (shape.py:109-126): t = (-beta - sqrt(Delta))/alpha if
@@ -244,14 +250,14 @@ struct SphereHit {
 // rate and each one less is ~1 us of k_bwd.  The forward kernels keep the plain square root.
 template <class T, bool WITH_IH = false>
 RRT_HD bool hit_sphere(const T r[3], const T o[3], SphereHit<T>& sh) {
-  sh.alpha = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-  sh.beta = r[0] * o[0] + r[1] * o[1] + r[2] * o[2];
+  sh.alpha = dot3<T>(r, r);
+  sh.beta = dot3<T>(r, o);
   sh.ia = m_rcp<T>(sh.alpha);
   sh.q = sh.beta * sh.ia;
-  sh.op[0] = o[0] - sh.q * r[0];
-  sh.op[1] = o[1] - sh.q * r[1];
-  sh.op[2] = o[2] - sh.q * r[2];
-  sh.Dp = T(1) - (sh.op[0] * sh.op[0] + sh.op[1] * sh.op[1] + sh.op[2] * sh.op[2]);
+  sh.op[0] = m_fma(-sh.q, r[0], o[0]);
+  sh.op[1] = m_fma(-sh.q, r[1], o[1]);
+  sh.op[2] = m_fma(-sh.q, r[2], o[2]);
+  sh.Dp = T(1) - dot3<T>(sh.op, sh.op);
   bool hit = sh.Dp > T(0);            // false for NaN, as the reference's mask
   const T x = (hit ? sh.Dp : T(1)) * sh.ia;
   if (WITH_IH) {
@@ -268,9 +274,9 @@ RRT_HD bool hit_sphere(const T r[3], const T o[3], SphereHit<T>& sh) {
 // Hit point in object space, p = o' + t r' = o_perp - h r' (shape.py:134).
 template <class T>
 RRT_HD void sphere_point(const SphereHit<T>& sh, const T r[3], T p[3]) {
-  p[0] = sh.op[0] - sh.h * r[0];
-  p[1] = sh.op[1] - sh.h * r[1];
-  p[2] = sh.op[2] - sh.h * r[2];
+  p[0] = m_fma(-sh.h, r[0], sh.op[0]);
+  p[1] = m_fma(-sh.h, r[1], sh.op[1]);
+  p[2] = m_fma(-sh.h, r[2], sh.op[2]);
 }
 
 // Square._hit (shape.py:25-40): t = -o_z/r_z, hit iff r_z != 0, t > 0 and the
@@ -279,8 +285,8 @@ template <class T>
 RRT_HD bool hit_square(const T r[3], const T o[3], T& t) {
   bool np = r[2] != T(0);
   t = -o[2] * m_rcp<T>(np ? r[2] : T(1));
-  T x = o[0] + t * r[0];
-  T y = o[1] + t * r[1];
+  T x = m_fma(t, r[0], o[0]);
+  T y = m_fma(t, r[1], o[1]);
   return np && (t > T(0)) && (x > T(-0.5)) && (x < T(0.5)) && (y > T(-0.5)) && (y < T(0.5));
 }
 
@@ -337,15 +343,16 @@ struct Hit {
 template <class T>
 RRT_HD void shade_phong(const T nu[3], const T colI[3], T ks, T kd, T ka, T sh, int powf,
                         int specular, const T L[3], const T look[3], T c[3]) {
-  T inv = m_rsqrt<T>(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]);
-  T n0 = nu[0] * inv, n1 = nu[1] * inv, n2 = nu[2] * inv;
-  T dd = -(n0 * L[0] + n1 * L[1] + n2 * L[2]);          // normals . (-Lhat), NOT clamped
-  T phi = ka + kd * dd;
+  T inv = m_rsqrt<T>(dot3<T>(nu, nu));
+  const T n[3] = {nu[0] * inv, nu[1] * inv, nu[2] * inv};
+  T dd = -dot3<T>(n, L);                                // normals . (-Lhat), NOT clamped
+  T phi = m_fma(kd, dd, ka);
   if (specular) {
     T two = T(2) * dd;
-    T s = (two * n0 + L[0]) * look[0] + (two * n1 + L[1]) * look[1] + (two * n2 + L[2]) * look[2];
+    const T rm[3] = {m_fma(two, n[0], L[0]), m_fma(two, n[1], L[1]), m_fma(two, n[2], L[2])};
+    T s = dot3<T>(rm, look);
     T pw1, l2;
-    phi += ks * pow_signed<T>(s, sh, powf, pw1, l2);
+    phi = m_fma(ks, pow_signed<T>(s, sh, powf, pw1, l2), phi);
   }
   for (int q = 0; q < 3; ++q) {
     T x = phi * colI[q];
@@ -360,15 +367,15 @@ RRT_HD void shade_phong(const T nu[3], const T colI[3], T ks, T kd, T ka, T sh, 
 template <class T, int SPEC>
 RRT_HD void shade_phong_fast(const T nu[3], const T colI[3], T ks, T kd, T ka, T sh, int powf,
                              const T L[3], const T look[3], T Llook, T c[3]) {
-  T inv = m_rsqrt<T>(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]);
-  T n0 = nu[0] * inv, n1 = nu[1] * inv, n2 = nu[2] * inv;
-  T ndl = n0 * L[0] + n1 * L[1] + n2 * L[2];            // dd = -ndl
-  T phi = ka - kd * ndl;
+  T inv = m_rsqrt<T>(dot3<T>(nu, nu));
+  const T n[3] = {nu[0] * inv, nu[1] * inv, nu[2] * inv};
+  T ndl = dot3<T>(n, L);                                // dd = -ndl
+  T phi = m_fma(-kd, ndl, ka);
   if (SPEC) {
-    T nlk = n0 * look[0] + n1 * look[1] + n2 * look[2];
-    T s = Llook - (ndl + ndl) * nlk;
+    T nlk = dot3<T>(n, look);
+    T s = m_fma(-(ndl + ndl), nlk, Llook);
     T e = m_exp2<T>(sh * m_log2<T>(abs_if<T>(s, (powf & POW_INT) != 0)));   // non-integer shininess: log2 of s < 0 is NaN, as pow()
-    phi += ks * sign_of_if<T>(e, s, (powf & POW_ODD) != 0);
+    phi = m_fma(ks, sign_of_if<T>(e, s, (powf & POW_ODD) != 0), phi);
   }
   for (int q = 0; q < 3; ++q) {
     T x = phi * colI[q];
@@ -378,7 +385,7 @@ RRT_HD void shade_phong_fast(const T nu[3], const T colI[3], T ks, T kd, T ka, T
 
 // DepthMapShader.shade (shader.py:14-20): 1 - t/maxDepth on all channels.
 template <class T>
-RRT_HD T shade_depth(T t, T inv_max_depth) { return T(1) - t * inv_max_depth; }
+RRT_HD T shade_depth(T t, T inv_max_depth) { return m_fma(-t, inv_max_depth, T(1)); }
 
 // --------------------------------------------------------------- adjoint --
 // Reverse-mode of one ray that hit shape `kind` (the composite winner), given

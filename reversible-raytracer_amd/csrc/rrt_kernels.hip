@@ -48,6 +48,9 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <type_traits>
+
 #include "rrt.h"
 #include "rrt_device.h"
 
@@ -86,17 +89,17 @@ __device__ unsigned long long* g_stamps = nullptr;   // [n_tiles][8]
     __builtin_amdgcn_sched_barrier(0);                                                      \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
     __builtin_amdgcn_sched_barrier(0);                                                      \
-    if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
+    if (g_stamps && lane == 0) g_stamps[tile * 16 + (slot)] = t_;                           \
   } while (0)
 #define RRT_STAMP_RT(slot)                                                                  \
   do {                                                                                      \
     unsigned long long t_;                                                                  \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
-    if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = t_;                            \
+    if (g_stamps && lane == 0) g_stamps[tile * 16 + (slot)] = t_;                           \
   } while (0)
 #define RRT_STAMP_VAL(slot, value)                                                          \
   do {                                                                                      \
-    if (g_stamps && lane == 0) g_stamps[tile * 8 + (slot)] = (unsigned long long)(value);   \
+    if (g_stamps && lane == 0) g_stamps[tile * 16 + (slot)] = (unsigned long long)(value);  \
   } while (0)
 // k_fwd: per-wave real-time stamps / counters in row `gw` (tools/stamp_fwd.py)
 #define RRT_STAMP_FWD(slot, value_or_rt)                                                    \
@@ -124,7 +127,11 @@ struct KArgs {
   const unsigned long long* mask; // [n_tiles][nwords]
   const unsigned long long* heavy; // [n_tiles] packed entries of tiles with >= 1 candidate (first counts[0])
   const unsigned long long* empty; // [n_tiles] packed entries of tiles with none           (first counts[1])
-  int lds_scene;                  // 1: B*S packed records fit the kernels' LDS staging area
+  int lds_scene;                  // 1: all B*S packed records fit the kernels' LDS staging area (and the LDS accumulators);
+                                  // 2: too many for that, but one SCENE's do: a workgroup takes whole list segments
+                                  //    (a segment lies in one scene), stages that scene and accumulates per segment;
+                                  // 0: neither (a scene of more than LDS_RECS shapes): scalar loads, global atomics
+  int bins_per_scene;             // list segments per scene
   const unsigned* blk_counts;     // [n_bins][2] per prep-block: #tiles with 3+ candidates | 2 candidates << 16,
                                   //             1 candidate | none << 16
   int n_bins;                     // prep workgroups = list segments of SEG slots
@@ -190,6 +197,12 @@ __device__ __forceinline__ unsigned long long lane_bcast64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Index of shape k of scene b in the LDS copy of the scene(s): the whole batch (lds_scene = 1) or only the
+// scene of the list segment the workgroup is working on (lds_scene = 2).
+__device__ __forceinline__ size_t lds_rec(const KArgs& a, int b, int k) {
+  return (size_t)(a.lds_scene == 2 ? 0 : b) * a.S + k;
+}
+
 // One shape's packed record as wave-uniform scalars (SGPRs).
 struct ShapeP {
   float A[9], o[3], colI[3], ks, kd, ka, sh;
@@ -203,7 +216,7 @@ struct ShapeP {
 // when the scene does not fit the staging area.
 __device__ __forceinline__ void load_shape(const KArgs& a, const float* lds, int b, int k, int lane, ShapeP& q) {
   if (a.lds_scene) {
-    const float v = lds[((size_t)b * a.S + k) * PS_STRIDE + (lane & 31)];
+    const float v = lds[lds_rec(a, b, k) * PS_STRIDE + (lane & 31)];
 #pragma unroll
     for (int n = 0; n < 9; ++n) q.A[n] = lane_bcast(v, PS_A + n);
 #pragma unroll
@@ -225,21 +238,38 @@ __device__ __forceinline__ void load_shape(const KArgs& a, const float* lds, int
   }
 }
 
+// The same in two steps, for callers that decide on kind / flags first and then want only a part:
+// `word` is the record as one VGPR (lane l holds word l); the pieces are v_readlane broadcasts of it.
+__device__ __forceinline__ float shape_word(const KArgs& a, const float* lds, int b, int k, int lane) {
+  return a.lds_scene ? lds[lds_rec(a, b, k) * PS_STRIDE + (lane & 31)]
+                     : a.ps[((size_t)b * a.S + k) * PS_STRIDE + (lane & 31)];
+}
+__device__ __forceinline__ void shape_head(float word, ShapeP& q) {
+  q.kind = ps_load_int(lane_bcast(word, PS_KIND));
+  q.powf = ps_load_int(lane_bcast(word, PS_POWF));
+}
+__device__ __forceinline__ void shape_material(float word, ShapeP& q) {
+#pragma unroll
+  for (int n = 0; n < 3; ++n) q.colI[n] = lane_bcast(word, PS_COLI + n);
+  q.ks = lane_bcast(word, PS_KS); q.kd = lane_bcast(word, PS_KD); q.ka = lane_bcast(word, PS_KA); q.sh = lane_bcast(word, PS_SH);
+  q.cmax = lane_bcast(word, PS_CMAX); q.kssh = lane_bcast(word, PS_KSSH);
+}
+__device__ __forceinline__ void shape_transform(float word, ShapeP& q) {
+#pragma unroll
+  for (int n = 0; n < 9; ++n) q.A[n] = lane_bcast(word, PS_A + n);
+#pragma unroll
+  for (int n = 0; n < 3; ++n) q.o[n] = lane_bcast(word, PS_O + n);
+}
+
 // The transform of a shape as per-lane VGPR copies (every lane reads the same LDS words: three
 // broadcast ds_read_b128, A' and o' are the first 12 words of the record).
-__device__ __forceinline__ void load_shape_vgpr(const KArgs& a, const float* lds, int b, int k, const ShapeP& q,
-                                                float Av[9], float ov[3]) {
-  if (a.lds_scene) {
-    const float4* r = reinterpret_cast<const float4*>(lds + ((size_t)b * a.S + k) * PS_STRIDE);
-    const float4 x0 = r[0], x1 = r[1], x2 = r[2];
-    Av[0] = x0.x; Av[1] = x0.y; Av[2] = x0.z; Av[3] = x0.w; Av[4] = x1.x; Av[5] = x1.y; Av[6] = x1.z; Av[7] = x1.w;
-    Av[8] = x2.x; ov[0] = x2.y; ov[1] = x2.z; ov[2] = x2.w;
-  } else {
-#pragma unroll
-    for (int n = 0; n < 9; ++n) Av[n] = q.A[n];
-#pragma unroll
-    for (int n = 0; n < 3; ++n) ov[n] = q.o[n];
-  }
+__device__ __forceinline__ void load_shape_vgpr(const KArgs& a, const float* lds, int b, int k, float Av[9], float ov[3]) {
+  // (from global memory when the scene is not staged: still every lane the same address, one request)
+  const float4* r = reinterpret_cast<const float4*>(a.lds_scene ? lds + lds_rec(a, b, k) * PS_STRIDE
+                                                                : a.ps + ((size_t)b * a.S + k) * PS_STRIDE);
+  const float4 x0 = r[0], x1 = r[1], x2 = r[2];
+  Av[0] = x0.x; Av[1] = x0.y; Av[2] = x0.z; Av[3] = x0.w; Av[4] = x1.x; Av[5] = x1.y; Av[6] = x1.z; Av[7] = x1.w;
+  Av[8] = x2.x; ov[0] = x2.y; ov[1] = x2.z; ov[2] = x2.w;
 #pragma unroll
   for (int n = 0; n < 9; ++n) asm volatile("" : "+v"(Av[n]));
 #pragma unroll
@@ -258,11 +288,17 @@ __device__ __forceinline__ void load_scene(const KArgs& a, int b, SceneP& sc) {
 }
 
 __device__ __forceinline__ void stage_scene(const KArgs& a, float* lds) {
-  if (a.lds_scene) {
+  if (a.lds_scene == 1) {
     const int n = a.B * a.S * PS_STRIDE;
     for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = a.ps[i];
   }
-  __syncthreads();       // the only workgroup barrier of the render kernels (once, before the tile loop)
+  __syncthreads();       // (once, before the tile loop)
+}
+// lds_scene = 2: the records of ONE scene (the scene of the list segment the workgroup turns to)
+__device__ __forceinline__ void stage_one_scene(const KArgs& a, float* lds, int b) {
+  const int n = a.S * PS_STRIDE;
+  const float* src = a.ps + (size_t)b * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = src[i];
 }
 
 // Ray generation, split so that what depends only on the lane stays out of the row loops
@@ -316,15 +352,15 @@ __device__ __forceinline__ void gen_rays(const KArgs& a, const Tile& t, const La
 // One candidate against this lane's P rays (scene.py:38-47: strict '<', the
 // caller visits candidates in list order so the first wins ties).
 template <int P, bool WANT_NU>
-__device__ __forceinline__ void trace_shape(const ShapeP& q, int k, const float d[P][3], int best[P], float tmin[P],
-                                            float nu[P][3]) {
-  if (q.kind == KIND_SPHERE) {
+__device__ __forceinline__ void trace_shape_p(int kind, const float* A, const float* o, int k, const float d[P][3],
+                                              int best[P], float tmin[P], float nu[P][3]) {
+  if (kind == KIND_SPHERE) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       float r[3];
-      xform_dir<float>(q.A, d[p], r);
+      xform_dir<float>(A, d[p], r);
       SphereHit<float> sp;
-      bool hit = hit_sphere<float>(r, q.o, sp);
+      bool hit = hit_sphere<float>(r, o, sp);
       if (hit && sp.t < tmin[p]) {
         tmin[p] = sp.t; best[p] = k;
         if (WANT_NU) sphere_point<float>(sp, r, nu[p]);
@@ -334,14 +370,19 @@ __device__ __forceinline__ void trace_shape(const ShapeP& q, int k, const float 
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       float r[3], t;
-      xform_dir<float>(q.A, d[p], r);
-      bool hit = hit_square<float>(r, q.o, t);
+      xform_dir<float>(A, d[p], r);
+      bool hit = hit_square<float>(r, o, t);
       if (hit && t < tmin[p]) {
         tmin[p] = t; best[p] = k;
-        if (WANT_NU) { nu[p][0] = 0.f; nu[p][1] = 0.f; nu[p][2] = q.o[2] > 0.f ? 1.f : -1.f; }
+        if (WANT_NU) { nu[p][0] = 0.f; nu[p][1] = 0.f; nu[p][2] = o[2] > 0.f ? 1.f : -1.f; }
       }
     }
   }
+}
+template <int P, bool WANT_NU>
+__device__ __forceinline__ void trace_shape(const ShapeP& q, int k, const float d[P][3], int best[P], float tmin[P],
+                                            float nu[P][3]) {
+  trace_shape_p<P, WANT_NU>(q.kind, q.A, q.o, k, d, best, tmin, nu);
 }
 
 template <int NW>
@@ -679,6 +720,8 @@ __device__ __forceinline__ unsigned long long zero_early_load(const KArgs& a, un
   return t % EARLY < size ? e : ~0ull;
 }
 
+__device__ __forceinline__ bool entry_is_multi(unsigned long long e) { return ((e >> 62) & 1u) != 0; }
+
 // One wave: next entry of the batch, or false when it is exhausted.
 __device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, unsigned long long& e) {
   unsigned i = 0;
@@ -764,33 +807,49 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
   SceneP sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
   QueueState qs;
   qs.next = qs.next_e = blockIdx.x;
-  for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
-    const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
-    if (bin0) {
-      __syncthreads();                     // previous batch fully consumed
-      cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
-      early = zero_early_load(a, bin0, nb);
-    }
-    if (threadIdx.x < (Q_CAP / SEG) * EARLY) s_z.early[threadIdx.x] = early;
-    const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
-    const unsigned cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave, [&] {
-      for (unsigned i = wave; i < (Q_CAP / SEG) * EARLY; i += WAVES) {
-        const unsigned long long e = lane_bcast64(s_z.early[i], 0);
-        if (e != ~0ull) zero_tile(e);
+  // lds_scene = 2 (a batch of many small scenes): no global deal -- the workgroup takes whole list segments
+  // (its own, blockIdx.x + i * gridDim.x), stages the segment's scene and works through the segment's entries
+  const bool local = a.lds_scene == 2;
+  for (unsigned bin0 = local ? blockIdx.x : 0u; bin0 < (unsigned)a.n_bins; bin0 += local ? gridDim.x : chunk) {
+    unsigned cnt, cnt_e;
+    if (local) {
+      if (bin0 != blockIdx.x) __syncthreads();               // previous segment fully consumed
+      const uint2 c = reinterpret_cast<const uint2*>(a.blk_counts)[bin0];
+      cnt = (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu);
+      cnt_e = c.y >> 16;
+      stage_one_scene(a, s_scene, (int)(bin0 / (unsigned)a.bins_per_scene));
+      if (threadIdx.x < cnt) s_q.ent[threadIdx.x] = a.heavy[(size_t)bin0 * SEG + threadIdx.x];
+      if (threadIdx.x < cnt_e) s_z.ent[threadIdx.x] = a.empty[(size_t)bin0 * SEG + threadIdx.x];
+      if (threadIdx.x == 0) { s_q.cursor = 0; s_z.cursor = 0; }
+      __syncthreads();
+    } else {
+      const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
+      if (bin0) {
+        __syncthreads();                     // previous batch fully consumed
+        cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
+        early = zero_early_load(a, bin0, nb);
       }
-    }, a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
-    const unsigned cnt_e = qs.cnt_e;
+      if (threadIdx.x < (Q_CAP / SEG) * EARLY) s_z.early[threadIdx.x] = early;
+      const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
+      cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave, [&] {
+        for (unsigned i = wave; i < (Q_CAP / SEG) * EARLY; i += WAVES) {
+          const unsigned long long e = lane_bcast64(s_z.early[i], 0);
+          if (e != ~0ull) zero_tile(e);
+        }
+      }, a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
+      cnt_e = qs.cnt_e;
+    }
     const unsigned per = cnt ? (cnt_e + cnt - 1) / cnt : 0;
     RRT_STAMP_FWD(1, ~0ull);
     unsigned long long e_cur;
     bool more_zero = cnt_e > 0;
-    // (a counted loop with a break: as `while (pop)` hipcc needed 13 more VGPRs and spilled)
-#pragma unroll 1
-    for (unsigned it = 0; it < cnt; ++it) {
-      if (!queue_pop(s_q, cnt, lane, e_cur)) break;
-      if (more_zero) more_zero = zero_fill(per, cnt_e);
-      int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, e_cur, k0, multi, tile);
+    // one tile; MULTI = several candidate shapes.  The queue is ordered by cost class, so a wave renders its
+    // multi-candidate tiles in one loop and the single-candidate ones in a second, leaner one
+    auto render_tile = [&](auto multi_tag) {
+      constexpr bool MULTI = decltype(multi_tag)::value;
+      int k0; bool multi_bit; long long tile;
+      const Tile t = decode_entry(a, e_cur, k0, multi_bit, tile);
+      (void)multi_bit;
       if (t.b != b_cur) {
         load_scene(a, t.b, sc);
         b_cur = t.b;
@@ -807,11 +866,14 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
         gen_rays<P, JC, TR>(a, t, lr, s, d);
 #pragma unroll
         for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
-        if (!multi) {
+        if (!MULTI) {
           // one candidate: its record is read once and serves trace and shading
+          // (its transform as per-lane VGPR copies: VALU instructions with an SGPR source issue at half rate)
           ShapeP q;
           load_shape(a, s_scene, t.b, k0, lane, q);
-          trace_shape<P, SHADER == SHADER_PHONG>(q, k0, d, best, tmin, nu);
+          float Av[9], ov[3];
+          load_shape_vgpr(a, s_scene, t.b, k0, Av, ov);
+          trace_shape_p<P, SHADER == SHADER_PHONG>(q.kind, Av, ov, k0, d, best, tmin, nu);
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             if (best[p] >= 0) {
@@ -879,6 +941,19 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
           }
         }
       }
+    };
+    bool have = queue_pop(s_q, cnt, lane, e_cur);
+#pragma unroll 1
+    while (have && entry_is_multi(e_cur)) {
+      if (more_zero) more_zero = zero_fill(per, cnt_e);
+      render_tile(std::true_type());
+      have = queue_pop(s_q, cnt, lane, e_cur);
+    }
+#pragma unroll 1
+    while (have) {
+      if (more_zero) more_zero = zero_fill(per, cnt_e);
+      render_tile(std::false_type());
+      have = queue_pop(s_q, cnt, lane, e_cur);
     }
     while (more_zero) more_zero = zero_fill(2, cnt_e);
   }
@@ -946,18 +1021,237 @@ template <int P>
 __device__ __forceinline__ void prefetch_grad_rows(const KArgs& a, const Tile& t, int lane, float* dst) {
   typedef const __attribute__((address_space(1))) void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
-  const int nd = t.ncols * 3, n16 = nd >> 2, tail = nd & 3;
+  // one address computation per tile, one add per row
+  const size_t row_bytes = (size_t)a.v.ncols * 12;
+  const char* row = reinterpret_cast<const char*>(a.grad) + ((size_t)t.b * a.v.rows + t.a0) * row_bytes + (size_t)t.b0 * 12;
+  if (t.ncols == TILE_W) {
+    // the usual case, a full-width tile: 48 lanes x 16 bytes per row
+    if (lane < TILE_W * 3 / 4) {
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    if (p < t.nrows) {
-      const float* row = a.grad + (((size_t)t.b * a.v.rows + t.a0 + p) * a.v.ncols + t.b0) * 3;
-      if (lane < n16) __builtin_amdgcn_global_load_lds((gptr)(row + 4 * lane), (lptr)(dst + p * UP_ROW), 16, 0, 0);
-      if (tail) {
+      for (int p = 0; p < P; ++p) {
+        if (p < t.nrows)
+          __builtin_amdgcn_global_load_lds((gptr)(row + p * row_bytes + 16 * lane), (lptr)(dst + p * UP_ROW), 16, 0, 0);
+      }
+    }
+  } else {
+    const int nd = t.ncols * 3, n16 = nd >> 2, tail = nd & 3;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (p < t.nrows) {
+        const char* r = row + p * row_bytes;
+        if (lane < n16) __builtin_amdgcn_global_load_lds((gptr)(r + 16 * lane), (lptr)(dst + p * UP_ROW), 16, 0, 0);
         if (lane < tail)
-          __builtin_amdgcn_global_load_lds((gptr)(row + 4 * n16 + lane), (lptr)(dst + p * UP_ROW + 4 * n16), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr)(r + 16 * n16 + 4 * lane), (lptr)(dst + p * UP_ROW + 4 * n16), 4, 0, 0);
       }
     }
   }
+}
+
+// A wave's position in its workgroup's queue, and what it carries from tile to tile.
+struct BwdWave {
+  unsigned long long e_cur, e_nxt;   // current entry, next entry (its gradient rows are in flight)
+  bool has_cur;
+  int buf;                           // which half of the wave's gradient double buffer holds the current tile's rows
+  int b_cur;                         // scene whose constants `sc` holds
+  SceneP sc;
+  // (only when the scene does not fit the LDS accumulators) the last global accumulator flush of a
+  // tile is held back into the next iteration: issued at the end of its tile it would sit in front of
+  // the next tile's wait for its (older) gradient rows -- the vector-memory counter retires in order
+  bool held;
+  int held_k, held_b;
+  float held_val;
+};
+
+// One tile of the backward pass.  MULTI = the tile has several candidate shapes: per sample, every
+// ray's winner is settled first and the adjoint then runs per winning shape.  !MULTI (two thirds of
+// the bench scene's tiles, and the cheap ones to get right): one candidate, no winner search, the
+// samples run INSIDE the accumulation, so the tile pays one butterfly.  A workgroup's queue is
+// ordered by cost class (3+ candidates, 2, 1), so a wave runs its MULTI tiles in one loop and its
+// single-candidate tiles in a second, leaner one (fewer live scalars: the general loop spills SGPRs).
+template <int P, int SHADER, int SPEC, int JC, int TR, bool MULTI>
+__device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_q, unsigned cnt, const float* s_scene,
+                                         float* s_acc, float* s_up_wave, int (*s_best_wave)[64], int lane) {
+  const ViewK& v = a.v;
+  int k0; bool multi_bit; long long tile;
+  const Tile t = decode_entry(a, w.e_cur, k0, multi_bit, tile);
+  (void)multi_bit;
+  RRT_STAMP(0);
+  RRT_STAMP_RT(14);
+  if (t.b != w.b_cur) {
+    load_scene(a, t.b, w.sc);
+    w.b_cur = t.b;
+  }
+  const SceneP& sc = w.sc;
+  const bool col_ok = lane < t.ncols;
+  // (1) this tile's gradient rows, requested one tile ago, have landed in the wave's buffer once its
+  // vector-memory counter is at zero (nothing younger is outstanding at this point)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RRT_STAMP(1);
+  const float* up_rows = s_up_wave + w.buf * (P * UP_ROW);
+  // (2) the accumulator atomic held back from the previous tile
+  if (w.held) {
+    if (lane < ACC_USED)
+      __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.held = false;
+  }
+  // (3) pull the next tile and request its gradient rows
+  const bool has_nxt = queue_pop(s_q, cnt, lane, w.e_nxt);
+  if (has_nxt) {
+    int k1; bool m1; long long tl1;
+    const Tile tn = decode_entry(a, w.e_nxt, k1, m1, tl1);
+    prefetch_grad_rows<P>(a, tn, lane, s_up_wave + (w.buf ^ 1) * (P * UP_ROW));
+  }
+  const LaneRay lr = lane_ray<TR>(a, t, lane);
+  cuptr mk = as_const(a.mask) + tile * a.nwords;
+  RRT_STAMP(2);
+
+#pragma unroll 1
+  for (int s0 = 0; s0 < (MULTI ? v.A : 1); ++s0) {
+    const int s_lo = MULTI ? s0 : 0, s_hi = MULTI ? s0 + 1 : v.A;
+    if (MULTI) {
+      const int s = s0;
+      // several candidates: settle every ray's winner first
+      float d[P][3], tmin[P];
+      int best[P];
+      gen_rays<P, JC, TR>(a, t, lr, s, d);
+#pragma unroll
+      for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
+      for (int wd = 0; wd < a.nwords; ++wd) {
+        unsigned long long m = mk[wd];
+        while (m) {
+          int k = wd * 64 + __builtin_ctzll(m);
+          m &= m - 1;
+          ShapeP q;
+          shape_head(shape_word(a, s_scene, t.b, k, lane), q);
+          float Av[9], ov[3];
+          load_shape_vgpr(a, s_scene, t.b, k, Av, ov);
+          trace_shape_p<P, false>(q.kind, Av, ov, k, d, best, tmin, nullptr);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) s_best_wave[p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
+    }
+    RRT_STAMP(3);
+    // walk the candidate shapes (one iteration for single-candidate tiles: the adjoint itself tests the hit)
+    int wd = 0;
+    unsigned long long m = MULTI ? mk[0] : 1ull;
+    while (true) {
+      while (MULTI && m == 0 && ++wd < a.nwords) m = mk[wd];
+      if (m == 0) break;
+      const int k = MULTI ? wd * 64 + __builtin_ctzll(m) : k0;
+      m &= m - 1;
+      if (MULTI) {
+        bool mine = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) mine |= (s_best_wave[p][lane] == k);
+        if (!__ballot(mine)) continue;
+      }
+      ShapeP q;
+      const float qword = shape_word(a, s_scene, t.b, k, lane);
+      shape_head(qword, q);
+      shape_material(qword, q);
+      float acc[ACC_USED];
+      // the empty asm pins each accumulator to one VGPR for the whole row loop: without it hipcc keeps
+      // two copies of the block and shuffles 30 registers around the loop
+#pragma unroll
+      for (int n = 0; n < ACC_USED; ++n) { acc[n] = 0.f; asm volatile("" : "+v"(acc[n])); }
+      bool anyhit = false;
+      RRT_STAMP(4);
+      if (SHADER == SHADER_PHONG && (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC))) {
+        // the hot path: a FAST_* Sphere (rrt_device.h: adjoint_sphere_phong).  Its most used uniforms --
+        // the transform, the light and view directions -- as per-lane VGPR copies: on gfx950 a VALU
+        // instruction with an SGPR source issues at about half the rate of one that reads only VGPRs
+        // (tools/ubench/issue_probe2.hip: v_fmac 2.4 vs 4.3 cycles at two waves per SIMD)
+        float Av[9], ov[3], Lv[3], lookv[3], shm1 = q.sh - 1.0f;
+        load_shape_vgpr(a, s_scene, t.b, k, Av, ov);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          Lv[n] = sc.L[n]; lookv[n] = sc.look[n];
+          asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
+        }
+        asm volatile("" : "+v"(shm1));
+#pragma unroll 1
+        for (int s = s_lo; s < s_hi; ++s) {
+          float jcx, jcy;
+          centre_jitter(v, s, jcx, jcy);
+#pragma unroll 1
+          for (int p = 0; p < t.nrows; ++p) {
+            const bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
+            if (on) {
+              float d[3];
+              row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+              const float* ur = up_rows + p * UP_ROW + 3 * lane;
+              const float up[3] = {ur[0], ur[1], ur[2]};
+              anyhit |= adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh, q.powf,
+                                                          Lv, lookv, sc.Llook, d, up, acc);
+            }
+          }
+        }
+      } else {
+        shape_transform(qword, q);
+#pragma unroll 1
+        for (int s = s_lo; s < s_hi; ++s) {
+          float jcx, jcy;
+          centre_jitter(v, s, jcx, jcy);
+#pragma unroll 1
+          for (int p = 0; p < t.nrows; ++p) {
+            const bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
+            if (on) {
+              float d[3];
+              row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+              const float* ur = up_rows + p * UP_ROW + 3 * lane;
+              const float up[3] = {ur[0], ur[1], ur[2]};
+              anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
+                                           v.inv_max_depth, sc.L, sc.look, d, up, acc);
+            }
+          }
+        }
+      }
+      RRT_STAMP(5);
+      if (!__ballot(anyhit)) continue;
+      // 22 per-lane partial sums -> 22 totals, as a transposing butterfly: a swap + an add folds TWO
+      // values across half the wave (v_permlane32_swap), then across rows (v_permlane16_swap); the six
+      // survivors carry four values each (one per 16-lane row) and finish with four DPP adds -- 59
+      // VALU ops instead of 22 full wave sums (176)
+      float r6[6];
+      wave_sums_22(acc, r6);
+      RRT_STAMP(6);
+      // every accumulator is linear in the upstream gradient: the 1/antialias_samples of the sample
+      // average (scene.py:50) is applied to the six sums instead of to every gradient row
+#pragma unroll
+      for (int n = 0; n < 6; ++n) r6[n] *= v.inv_A;
+      if (a.lds_scene) {
+        // row j of r6[m] holds total m + {0,6,11,17}[j] in its last lane (r6[5]: rows 0 and 2 only)
+        float* row = &s_acc[lds_rec(a, t.b, k) * ACC_STRIDE + (lane >> 4) * 6 - (lane >> 5)];
+        if ((lane & 15) == 15) {
+#pragma unroll
+          for (int n = 0; n < 5; ++n) atomicAdd(row + n, r6[n]);
+          if (!(lane & 16)) atomicAdd(row + 5, r6[5]);
+        }
+      } else {
+        float mine_val = 0.f;
+#pragma unroll
+        for (int n = 0; n < ACC_USED; ++n) {
+          const int mm = n < 6 ? n : (n < 11 ? n - 6 : (n < 16 ? n - 11 : (n == 16 ? 5 : n - 17)));
+          const int j = n < 6 ? 0 : (n < 11 ? 1 : (n < 17 ? 2 : 3));
+          const float bc = lane_bcast(r6[mm], 16 * j + 15);
+          mine_val = (lane == n) ? bc : mine_val;
+        }
+        if (w.held && lane < ACC_USED)
+          __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w.held = true; w.held_k = k; w.held_b = t.b; w.held_val = mine_val;
+      }
+      RRT_STAMP(7);
+      RRT_STAMP_VAL(13, blockIdx.x);
+    }
+  }
+  RRT_STAMP(8);
+  RRT_STAMP_RT(15);
+  w.e_cur = w.e_nxt;
+  w.has_cur = has_nxt;
+  w.buf ^= 1;
 }
 
 // Persistent over the tiles that have candidates (tiles without never touch
@@ -996,238 +1290,93 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   } else if (threadIdx.x < min(chunk, (unsigned)a.n_bins)) {
     cw = reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x];
   }
-  if (a.lds_scene)
+  if (a.lds_scene == 1)
     for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
   stage_scene(a, s_scene);          // ends with the workgroup barrier
-  int b_cur = -1;
-  SceneP sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
-  // (only when the scene does not fit the LDS accumulators) the last global accumulator
-  // flush of a tile is held back into the next iteration: issued at the end of its tile it
-  // would sit in front of the next tile's wait for its (older) gradient loads -- the
-  // vector-memory counter retires in order
-  bool held = false;
-  int held_k = 0, held_b = 0;
-  float held_val = 0.f;
+  BwdWave w;
+  w.e_cur = w.e_nxt = 0; w.has_cur = false; w.buf = 0; w.b_cur = -1;
+  w.sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
+  w.held = false; w.held_k = w.held_b = 0; w.held_val = 0.f;
+  float* const s_up_wave = &s_up[wave][0][0][0];
+  int (*const s_best_wave)[64] = s_best[wave];
 
   QueueState qs;
   qs.next = blockIdx.x;
-  for (unsigned bin0 = 0; bin0 < (unsigned)a.n_bins; bin0 += chunk) {
-    const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
-    const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
-    if (bin0) {
-      __syncthreads();                     // previous batch fully consumed
-      if (a.use_saved) {
-        saved_cnt = as_const_u32(a.wgq_cnt)[slot];
-        saved_ent = threadIdx.x < saved_cnt ? a.wgq[slot * Q_CAP + threadIdx.x] : 0ull;
-      } else {
-        cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
-      }
-    }
+  // lds_scene = 2 (a batch of many small scenes): the workgroup takes whole list segments, stages the segment's
+  // scene, accumulates the segment's gradient in LDS and adds it to HBM when the segment is done
+  const bool local = a.lds_scene == 2;
+  for (unsigned bin0 = local ? blockIdx.x : 0u; bin0 < (unsigned)a.n_bins; bin0 += local ? gridDim.x : chunk) {
     unsigned cnt;
-    if (a.use_saved) {
-      // the forward pass on this setup dealt exactly this share: one contiguous read
-      cnt = saved_cnt;
-      if (threadIdx.x < cnt) s_q.ent[threadIdx.x] = saved_ent;
+    if (local) {
+      if (bin0 != blockIdx.x) {
+        __syncthreads();                     // every wave is done adding to the LDS rows of the previous segment
+        const int bp = (int)((bin0 - gridDim.x) / (unsigned)a.bins_per_scene);
+        for (int i = threadIdx.x; i < a.S * ACC_STRIDE; i += blockDim.x) {
+          const float x = s_acc[i];
+          if ((i & (ACC_STRIDE - 1)) < ACC_USED && x != 0.f)
+            __hip_atomic_fetch_add(a.acc + (size_t)bp * a.S * ACC_STRIDE + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+      const uint2 c = reinterpret_cast<const uint2*>(a.blk_counts)[bin0];
+      cnt = (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu);
+      stage_one_scene(a, s_scene, (int)(bin0 / (unsigned)a.bins_per_scene));
+      for (int i = threadIdx.x; i < a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
+      if (threadIdx.x < cnt) s_q.ent[threadIdx.x] = a.heavy[(size_t)bin0 * SEG + threadIdx.x];
       if (threadIdx.x == 0) s_q.cursor = 0;
       __syncthreads();
     } else {
-      cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave, NoHook(),
-                              a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
-    }
-    unsigned long long e_cur = 0, e_nxt = 0;
-    bool has_cur = queue_pop(s_q, cnt, lane, e_cur);
-    int buf = 0;
-    if (has_cur) {
-      int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, e_cur, k0, multi, tile);
-      prefetch_grad_rows<P>(a, t, lane, &s_up[wave][0][0][0]);
-    }
-    while (has_cur) {
-      int k0; bool multi; long long tile;
-      const Tile t = decode_entry(a, e_cur, k0, multi, tile);
-      RRT_STAMP(0);
-      RRT_STAMP_RT(7);
-      if (t.b != b_cur) {
-        load_scene(a, t.b, sc);
-        b_cur = t.b;
-      }
-      const bool col_ok = lane < t.ncols;
-      // (1) this tile's gradient rows, requested one tile ago, have landed in s_up[wave][buf] once the wave's
-      // vector-memory counter is at zero (nothing younger is outstanding at this point)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const float* up_rows = &s_up[wave][buf][0][0];
-      // (2) the accumulator atomic held back from the previous tile
-      if (held) {
-        if (lane < ACC_USED)
-          __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val,
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        held = false;
-      }
-      // (3) pull the next tile and request its gradient rows
-      const bool has_nxt = queue_pop(s_q, cnt, lane, e_nxt);
-      if (has_nxt) {
-        int k1; bool m1; long long tl1;
-        const Tile tn = decode_entry(a, e_nxt, k1, m1, tl1);
-        prefetch_grad_rows<P>(a, tn, lane, &s_up[wave][buf ^ 1][0][0]);
-      }
-      const LaneRay lr = lane_ray<TR>(a, t, lane);
-      cuptr mk = as_const(a.mask) + tile * a.nwords;
-      RRT_STAMP(1);
-
-      // several candidates: per sample, settle every ray's winner, then run the adjoint per winning shape.
-      // One candidate: the samples run INSIDE the accumulation, so the tile pays one butterfly, not one per sample.
-#pragma unroll 1
-      for (int s0 = 0; s0 < (multi ? v.A : 1); ++s0) {
-        const int s_lo = multi ? s0 : 0, s_hi = multi ? s0 + 1 : v.A;
-        if (multi) {
-          const int s = s0;
-          // several candidates: settle every ray's winner first
-          float d[P][3], tmin[P];
-          int best[P];
-          gen_rays<P, JC, TR>(a, t, lr, s, d);
-#pragma unroll
-          for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
-          for (int w = 0; w < a.nwords; ++w) {
-            unsigned long long m = mk[w];
-            while (m) {
-              int k = w * 64 + __builtin_ctzll(m);
-              m &= m - 1;
-              ShapeP q;
-              load_shape(a, s_scene, t.b, k, lane, q);
-              trace_shape<P, false>(q, k, d, best, tmin, nullptr);
-            }
-          }
-#pragma unroll
-          for (int p = 0; p < P; ++p) s_best[wave][p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
-        }
-        RRT_STAMP(2);
-        // walk the candidate shapes (one iteration for single-candidate tiles:
-        // the adjoint itself tests the hit)
-        int w = 0;
-        unsigned long long m = multi ? mk[0] : 1ull;
-        while (true) {
-          while (multi && m == 0 && ++w < a.nwords) m = mk[w];
-          if (m == 0) break;
-          const int k = multi ? w * 64 + __builtin_ctzll(m) : k0;
-          m &= m - 1;
-          if (multi) {
-            bool mine = false;
-#pragma unroll
-            for (int p = 0; p < P; ++p) mine |= (s_best[wave][p][lane] == k);
-            if (!__ballot(mine)) continue;
-          }
-          ShapeP q;
-          load_shape(a, s_scene, t.b, k, lane, q);
-          float acc[ACC_USED];
-          // the empty asm pins each accumulator to one VGPR for the whole row loop: without it
-          // hipcc keeps two copies of the block and shuffles 30 registers around the loop
-          // (160 -> 128 VGPRs, i.e. 3 -> 4 waves per SIMD)
-#pragma unroll
-          for (int n = 0; n < ACC_USED; ++n) { acc[n] = 0.f; asm volatile("" : "+v"(acc[n])); }
-          bool anyhit = false;
-          RRT_STAMP(3);
-          if (SHADER == SHADER_PHONG && (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC))) {
-            // the hot path: a FAST_* Sphere (rrt_device.h: adjoint_sphere_phong).  Its most used uniforms --
-            // the transform, the light and view directions -- as per-lane VGPR copies: on gfx950 a VALU
-            // instruction with an SGPR source issues at about half the rate of one that reads only VGPRs
-            // (tools/ubench/issue_probe2.hip: v_fmac 2.4 vs 4.3 cycles at two waves per SIMD)
-            float Av[9], ov[3], Lv[3], lookv[3], shm1 = q.sh - 1.0f;
-            load_shape_vgpr(a, s_scene, t.b, k, q, Av, ov);
-#pragma unroll
-            for (int n = 0; n < 3; ++n) {
-              Lv[n] = sc.L[n]; lookv[n] = sc.look[n];
-              asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
-            }
-            asm volatile("" : "+v"(shm1));
-#pragma unroll 1
-            for (int s = s_lo; s < s_hi; ++s) {
-              float jcx, jcy;
-              centre_jitter(v, s, jcx, jcy);
-#pragma unroll 1
-              for (int p = 0; p < t.nrows; ++p) {
-                const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
-                if (on) {
-                  float d[3];
-                  row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
-                  const float* ur = up_rows + p * UP_ROW + 3 * lane;
-                  const float up[3] = {ur[0], ur[1], ur[2]};
-                  anyhit |= adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh,
-                                                              q.powf, Lv, lookv, sc.Llook, d, up, acc);
-                }
-              }
-            }
-          } else {
-#pragma unroll 1
-            for (int s = s_lo; s < s_hi; ++s) {
-              float jcx, jcy;
-              centre_jitter(v, s, jcx, jcy);
-#pragma unroll 1
-              for (int p = 0; p < t.nrows; ++p) {
-                const bool on = multi ? (s_best[wave][p][lane] == k) : col_ok;
-                if (on) {
-                  float d[3];
-                  row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
-                  const float* ur = up_rows + p * UP_ROW + 3 * lane;
-                  const float up[3] = {ur[0], ur[1], ur[2]};
-                  anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
-                                               v.inv_max_depth, sc.L, sc.look, d, up, acc);
-                }
-              }
-            }
-          }
-          RRT_STAMP(4);
-          if (!__ballot(anyhit)) continue;
-          // 22 per-lane partial sums -> 22 totals, as a transposing butterfly: a swap + an add
-          // folds TWO values across half the wave (v_permlane32_swap), then across rows
-          // (v_permlane16_swap); the six survivors carry four values each (one per 16-lane row)
-          // and finish with four DPP adds -- 59 VALU ops instead of 22 full wave sums (176)
-          float r6[6];
-          wave_sums_22(acc, r6);
-          // every accumulator is linear in the upstream gradient: the 1/antialias_samples of the
-          // sample average (scene.py:50) is applied to the six sums instead of to every gradient row
-#pragma unroll
-          for (int m = 0; m < 6; ++m) r6[m] *= v.inv_A;
-          if (a.lds_scene) {
-            // row j of r6[m] holds total m + {0,6,11,17}[j] in its last lane (r6[5]: rows 0 and 2 only)
-            float* row = &s_acc[((size_t)t.b * a.S + k) * ACC_STRIDE + (lane >> 4) * 6 - (lane >> 5)];
-            if ((lane & 15) == 15) {
-#pragma unroll
-              for (int m = 0; m < 5; ++m) atomicAdd(row + m, r6[m]);
-              if (!(lane & 16)) atomicAdd(row + 5, r6[5]);
-            }
-          } else {
-            float mine_val = 0.f;
-#pragma unroll
-            for (int n = 0; n < ACC_USED; ++n) {
-              const int m = n < 6 ? n : (n < 11 ? n - 6 : (n < 16 ? n - 11 : (n == 16 ? 5 : n - 17)));
-              const int j = n < 6 ? 0 : (n < 11 ? 1 : (n < 17 ? 2 : 3));
-              const float bc = lane_bcast(r6[m], 16 * j + 15);
-              mine_val = (lane == n) ? bc : mine_val;
-            }
-            if (held && lane < ACC_USED)
-              __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val,
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            held = true; held_k = k; held_b = t.b; held_val = mine_val;
-          }
-          RRT_STAMP_VAL(5, blockIdx.x);
+      const unsigned nb = min(chunk, (unsigned)a.n_bins - bin0);
+      const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
+      if (bin0) {
+        __syncthreads();                     // previous batch fully consumed
+        if (a.use_saved) {
+          saved_cnt = as_const_u32(a.wgq_cnt)[slot];
+          saved_ent = threadIdx.x < saved_cnt ? a.wgq[slot * Q_CAP + threadIdx.x] : 0ull;
+        } else {
+          cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
         }
       }
-      RRT_STAMP(6);
-      RRT_STAMP_RT(2);     // overwrites the phase-1 stamp: real time at the end of the tile
-      e_cur = e_nxt;
-      has_cur = has_nxt;
-      buf ^= 1;
+      if (a.use_saved) {
+        // the forward pass on this setup dealt exactly this share: one contiguous read
+        cnt = saved_cnt;
+        if (threadIdx.x < cnt) s_q.ent[threadIdx.x] = saved_ent;
+        if (threadIdx.x == 0) s_q.cursor = 0;
+        __syncthreads();
+      } else {
+        cnt = queue_fill<false>(s_q, nullptr, a.heavy, nullptr, cw, bin0, nb, qs, lane, wave, NoHook(),
+                                a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
+      }
     }
+    w.has_cur = queue_pop(s_q, cnt, lane, w.e_cur);
+    w.buf = 0;
+    if (w.has_cur) {
+      int k0; bool multi; long long tile;
+      const Tile t = decode_entry(a, w.e_cur, k0, multi, tile);
+      prefetch_grad_rows<P>(a, t, lane, s_up_wave);
+    }
+    // the queue is ordered by cost class: first the tiles with several candidates, then the others
+    while (w.has_cur && entry_is_multi(w.e_cur))
+      bwd_tile<P, SHADER, SPEC, JC, TR, true>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
+    // (queue_fill stages a workgroup's share in list order -- class 0, 1, 2 -- and the saved batches keep
+    // that order: no entry with several candidates follows one with a single candidate)
+    while (w.has_cur)
+      bwd_tile<P, SHADER, SPEC, JC, TR, false>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
   }
-  if (held && lane < ACC_USED)
-    __hip_atomic_fetch_add(a.acc + ((size_t)held_b * a.S + held_k) * ACC_STRIDE + lane, held_val, __ATOMIC_RELAXED,
+  if (w.held && lane < ACC_USED)
+    __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
   if (a.lds_scene) {
     __syncthreads();                 // every wave of the workgroup is done adding
-    for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) {
+    // lds_scene = 2: the rows of the LAST segment this workgroup worked on (if it had any)
+    const unsigned last = local && blockIdx.x < (unsigned)a.n_bins
+                              ? blockIdx.x + ((unsigned)a.n_bins - 1u - blockIdx.x) / gridDim.x * gridDim.x : 0u;
+    const int n = local ? (blockIdx.x < (unsigned)a.n_bins ? a.S * ACC_STRIDE : 0) : a.B * a.S * ACC_STRIDE;
+    float* dst = a.acc + (local ? (size_t)(last / (unsigned)a.bins_per_scene) * a.S * ACC_STRIDE : 0);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const float x = s_acc[i];
       if ((i & (ACC_STRIDE - 1)) < ACC_USED && x != 0.f)
-        __hip_atomic_fetch_add(a.acc + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(dst + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1288,44 +1437,102 @@ __global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, cons
     }
     return;
   }
-  if (g_w2o) {
-    for (int idx = tid; idx < Bw * S; idx += blockDim.x) {
-      int bw = idx / S, k = idx - bw * S;
-      float gw[12];
-      for (int n = 0; n < 12; ++n) gw[n] = 0.f;
-      int blo = w2o_bs ? bw : 0, bhi = w2o_bs ? bw + 1 : B;
-      for (int b = blo; b < bhi; ++b)
-        finalize_w2o<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, hdr + (size_t)b * HDR_STRIDE, gw);
-      for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
-    }
-  }
-  if (g_mat) {
-    for (int idx = tid; idx < Bm * S; idx += blockDim.x) {
-      int bm = idx / S, k = idx - bm * S;
-      float gm[7];
-      for (int n = 0; n < 7; ++n) gm[n] = 0.f;
-      int blo = mat_bs ? bm : 0, bhi = mat_bs ? bm + 1 : B;
-      for (int b = blo; b < bhi; ++b) finalize_material<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, light, gm);
-      for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
-    }
-  }
-  if (g_light) {
+  // Shared (batch stride 0) transforms or materials: their gradient is the sum over the scenes.  Every
+  // thread chains one (scene, shape) row and adds it to LDS sums (a serial loop over the scenes per shape
+  // made the 256-scene orbit batch spend 30 us here); beyond FIN_S shapes the serial loops remain.
+  constexpr int FIN_S = 256;
+  __shared__ float s_gw[FIN_S * 12];
+  __shared__ float s_gm[FIN_S * 7];
+  if (S <= FIN_S) {
+    if (g_w2o && !w2o_bs)
+      for (int i = tid; i < S * 12; i += blockDim.x) s_gw[i] = 0.f;
+    if (g_mat && !mat_bs)
+      for (int i = tid; i < S * 7; i += blockDim.x) s_gm[i] = 0.f;
+    __syncthreads();
     float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int idx = tid; idx < B * S; idx += blockDim.x) {
-      int b = idx / S, k = idx - b * S;
-      finalize_light_accum<float>(acc + (size_t)idx * ACC_STRIDE, mat + b * mat_bs + 7 * k, gl);
-    }
+      const int b = idx / S, k = idx - b * S;
+      float row[ACC_STRIDE];
+      const float4* src = reinterpret_cast<const float4*>(acc + (size_t)idx * ACC_STRIDE);
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
-      const float tot = wave_sum_to_lane63(gl[n]);
-      if (lane == 63) s_red[wave][n] = tot;
+      for (int q = 0; q < ACC_STRIDE / 4; ++q) {
+        const float4 x = src[q];
+        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+      }
+      if (g_w2o) {
+        float gw[12];
+        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+        finalize_w2o<float>(row, hdr + (size_t)b * HDR_STRIDE, gw);
+        if (w2o_bs) { for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n]; }
+        else { for (int n = 0; n < 12; ++n) atomicAdd(&s_gw[k * 12 + n], gw[n]); }
+      }
+      if (g_mat) {
+        float gm[7];
+        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+        finalize_material<float>(row, light, gm);
+        if (mat_bs) { for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n]; }
+        else { for (int n = 0; n < 7; ++n) atomicAdd(&s_gm[k * 7 + n], gm[n]); }
+      }
+      if (g_light) finalize_light_accum<float>(row, mat + b * mat_bs + 7 * k, gl);
+    }
+    if (g_light) {
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const float tot = wave_sum_to_lane63(gl[n]);
+        if (lane == 63) s_red[wave][n] = tot;
+      }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (g_w2o && !w2o_bs)
+      for (int i = tid; i < S * 12; i += blockDim.x) g_w2o[i] = s_gw[i];
+    if (g_mat && !mat_bs)
+      for (int i = tid; i < S * 7; i += blockDim.x) g_mat[i] = s_gm[i];
+    if (g_light && tid == 0) {
       float g[6];
       for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
       finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
       for (int n = 0; n < 6; ++n) g_light[n] = g[n];
+    }
+  } else {
+    if (g_w2o) {
+      for (int idx = tid; idx < Bw * S; idx += blockDim.x) {
+        int bw = idx / S, k = idx - bw * S;
+        float gw[12];
+        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+        int blo = w2o_bs ? bw : 0, bhi = w2o_bs ? bw + 1 : B;
+        for (int b = blo; b < bhi; ++b)
+          finalize_w2o<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, hdr + (size_t)b * HDR_STRIDE, gw);
+        for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
+      }
+    }
+    if (g_mat) {
+      for (int idx = tid; idx < Bm * S; idx += blockDim.x) {
+        int bm = idx / S, k = idx - bm * S;
+        float gm[7];
+        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+        int blo = mat_bs ? bm : 0, bhi = mat_bs ? bm + 1 : B;
+        for (int b = blo; b < bhi; ++b) finalize_material<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, light, gm);
+        for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
+      }
+    }
+    if (g_light) {
+      float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int idx = tid; idx < B * S; idx += blockDim.x) {
+        int b = idx / S, k = idx - b * S;
+        finalize_light_accum<float>(acc + (size_t)idx * ACC_STRIDE, mat + b * mat_bs + 7 * k, gl);
+      }
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const float tot = wave_sum_to_lane63(gl[n]);
+        if (lane == 63) s_red[wave][n] = tot;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float g[6];
+        for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
+        finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
+        for (int n = 0; n < 6; ++n) g_light[n] = g[n];
+      }
     }
   }
   __syncthreads();                                   // every read of acc is done
@@ -1348,34 +1555,49 @@ struct Geometry {
   long long n_tiles, n_bins;
   size_t ps_off, hdr_off, acc_off, counts_off, mask_off, heavy_off, empty_off, wgq_off, wgq_cnt_off, total;
   unsigned blocks_fwd, blocks_bwd;   // persistent grids of the render kernels
+  int lds_mode;                      // KArgs::lds_scene
   int chunk;                         // list segments per queue batch
 };
 
-// Rows per wave tile.  P = 4 (64x4-pixel tiles) once the launch has enough
-// tiles to fill the chip, otherwise fewer rows to expose more waves.
-// RRT_TUNE_P=1|2|4 overrides (tuning experiments only).
-int tuned_P() {
-  static int cached = -1;
-  if (cached < 0) {
-    const char* e = getenv("RRT_TUNE_P");
-    int p = e ? atoi(e) : 0;
-    cached = (p == 1 || p == 2 || p == 4) ? p : 0;
-  }
-  return cached;
+// RRT_TUNE_* environment variables (tuning experiments and tests only), read ONCE per process -- not on
+// every call of the product path.  Tests that change them call rrt_debug_reload_tuning().
+struct Tune {
+  int P = 0;              // RRT_TUNE_P=1|2|4: rows per wave tile
+  int fwd_wgs = 0, bwd_wgs = 0, chunk = 0;
+  bool no_lds = false, no_saved = false;
+};
+Tune g_tune;
+std::once_flag g_tune_once;
+void read_tune(Tune& x) {
+  auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+  const int p = num("RRT_TUNE_P");
+  x.P = (p == 1 || p == 2 || p == 4) ? p : 0;
+  x.fwd_wgs = num("RRT_TUNE_FWD_WGS");
+  x.bwd_wgs = num("RRT_TUNE_BWD_WGS");
+  x.chunk = num("RRT_TUNE_CHUNK");
+  x.no_lds = getenv("RRT_TUNE_NOLDS") != nullptr;
+  x.no_saved = getenv("RRT_TUNE_NOSAVED") != nullptr;
 }
+const Tune& tune() {
+  std::call_once(g_tune_once, [] { read_tune(g_tune); });
+  return g_tune;
+}
+int tuned_P() { return tune().P; }
 
-// Persistent launches: enough workgroups to fill every CU at the kernels'
-// register-limited occupancy, never more than there are tiles.
+// Persistent launches: enough workgroups to fill every CU at the kernels' register-limited occupancy,
+// never more than there are tiles.  The CU count is looked up once per device.
 int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cus[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
+    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
   }
-  return cus;
+  return cus[dev];
 }
 
 unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
@@ -1385,11 +1607,6 @@ unsigned persistent_blocks(long long n_tiles, int wgs_per_cu) {
   return (unsigned)(want < need ? want : need);
 }
 
-int tuned_wgs(const char* name, int dflt) {
-  const char* e = getenv(name);
-  int x = e ? atoi(e) : 0;
-  return x > 0 ? x : dflt;
-}
 
 Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   Geometry g;
@@ -1411,13 +1628,20 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
   g.empty_off = g.heavy_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long);
   // saved queue batches: one Q_CAP-entry slot per (batch of list segments, workgroup)
-  g.blocks_fwd = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_FWD_WGS", 1));
-  g.blocks_bwd = persistent_blocks(g.n_tiles, tuned_wgs("RRT_TUNE_BWD_WGS", 1));
+  g.blocks_fwd = persistent_blocks(g.n_tiles, tune().fwd_wgs > 0 ? tune().fwd_wgs : 1);
+  g.blocks_bwd = persistent_blocks(g.n_tiles, tune().bwd_wgs > 0 ? tune().bwd_wgs : 1);
+  // where the packed scene and the gradient accumulators live while the render kernels run (KArgs::lds_scene)
+  const long long recs = (long long)s->B * s->S;
+  g.lds_mode = tune().no_lds ? 0 : (recs <= LDS_RECS ? 1 : (s->S <= LDS_RECS ? 2 : 0));
+  if (g.lds_mode == 2) {             // a workgroup per list segment at a time
+    if ((long long)g.blocks_fwd > g.n_bins) g.blocks_fwd = (unsigned)g.n_bins;
+    if ((long long)g.blocks_bwd > g.n_bins) g.blocks_bwd = (unsigned)g.n_bins;
+  }
   const unsigned blocks = g.blocks_fwd > g.blocks_bwd ? g.blocks_fwd : g.blocks_bwd;
   const unsigned fewest = g.blocks_fwd < g.blocks_bwd ? g.blocks_fwd : g.blocks_bwd;
   long long chunk = (long long)Q_CAP * fewest / SEG;
   chunk = chunk < 1 ? 1 : (chunk > BLOCK ? BLOCK : chunk);
-  const int forced = tuned_wgs("RRT_TUNE_CHUNK", 0);           // tests: several batches at small sizes
+  const int forced = tune().chunk;                             // tests: several batches at small sizes
   if (forced > 0 && forced < chunk) chunk = forced;
   g.chunk = (int)chunk;
   const size_t slots = (size_t)((g.n_bins + chunk - 1) / chunk) * blocks;
@@ -1478,7 +1702,8 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.mask = (const unsigned long long*)(base + g.mask_off);
   a.heavy = (const unsigned long long*)(base + g.heavy_off);
   a.empty = (const unsigned long long*)(base + g.empty_off);
-  a.lds_scene = ((long long)s->B * s->S <= LDS_RECS && !getenv("RRT_TUNE_NOLDS")) ? 1 : 0;
+  a.lds_scene = g.lds_mode;
+  a.bins_per_scene = (int)(g.n_bins / (s->B > 0 ? s->B : 1));
   a.blk_counts = (const unsigned*)(base + g.counts_off);
   a.n_bins = (int)g.n_bins;
   a.wgq = (unsigned long long*)(base + g.wgq_off);
@@ -1549,6 +1774,13 @@ int rrt_debug_set_stamps(void* dev_ptr) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
 }
 #endif
+
+// Tests only (not part of rrt.h): read the RRT_TUNE_* environment again.  Not safe against concurrent renders.
+int rrt_debug_reload_tuning(void) {
+  tune();
+  read_tune(g_tune);
+  return 0;
+}
 
 int rrt_version(void) { return RRT_VERSION; }
 
@@ -1635,7 +1867,7 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
     unsigned blocks = g.blocks_bwd;
     a.n_waves = (int)blocks * WAVES;
     // the kernel that ran on this setup before (forward or backward) left its queue batches behind
-    a.use_saved = ((v->flags & RRT_FLAG_REUSE_SETUP) && g.blocks_fwd == g.blocks_bwd && !getenv("RRT_TUNE_NOSAVED")) ? 1 : 0;
+    a.use_saved = ((v->flags & RRT_FLAG_REUSE_SETUP) && g.blocks_fwd == g.blocks_bwd && g.lds_mode != 2 && !tune().no_saved) ? 1 : 0;
     if (g.P == 4) launch_bwd<4>(a, blocks, a.v.shader, a.v.specular, st);
     else if (g.P == 2) launch_bwd<2>(a, blocks, a.v.shader, a.v.specular, st);
     else launch_bwd<1>(a, blocks, a.v.shader, a.v.specular, st);

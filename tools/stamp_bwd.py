@@ -49,7 +49,7 @@ for _ in range(3):
     job.fwd(); job.bwd()
 torch.cuda.synchronize()
 n_tiles = (args.size // 64) * (args.size // 4)
-stamps = torch.zeros((n_tiles + 64, 8), dtype=torch.int64, device=dev)
+stamps = torch.zeros((n_tiles + 64, 16), dtype=torch.int64, device=dev)
 job.fwd()
 torch.cuda.synchronize()
 rc = job.L.rrt_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))     # after the forward: k_fwd stamps the same buffer
@@ -57,32 +57,39 @@ assert rc == 0, rc
 job.bwd()
 torch.cuda.synchronize()
 st = stamps.cpu().numpy()[:n_tiles]
-heavy = st[:, 6] != 0
+heavy = st[:, 8] != 0
 h = st[heavy].astype(np.float64)
 print("tiles", n_tiles, "non-empty", heavy.sum())
-names = ["0->1 grad wait + LDS stage + prefetch issue", "(slot 2 holds the end-of-tile real time)",
-         "(slot 2 holds the end-of-tile real time)", "3->4 adjoint rows"]
-tot = h[:, 6] - h[:, 0]
-print("total cycles/wave: median %.0f mean %.0f p90 %.0f" % (np.median(tot), tot.mean(), np.percentile(tot, 90)))
+# slots: 0 tile start | 1 gradient rows landed (vmcnt 0) | 2 next tile popped + its prefetch issued |
+#        3 winners settled (multi-candidate tiles) | 4 shape loaded, accumulators zeroed | 5 rows done |
+#        6 butterfly done | 7 LDS accumulation issued (last shape of the tile) | 8 tile end
+#        13 workgroup id | 14 / 15 real time (100 MHz) at tile start / end
+names = ["0->1 wait for this tile's gradient rows", "1->2 pop next tile + issue its prefetch", "2->3 winner search (multi) ",
+         "3->4 shape load + accumulator init (last shape)", "4->5 adjoint rows (last shape)", "5->6 butterfly", "6->7 LDS accumulation",
+         "7->8 tile epilogue"]
+tot = h[:, 8] - h[:, 0]
+print("total cycles/tile: median %.0f mean %.0f p90 %.0f" % (np.median(tot), tot.mean(), np.percentile(tot, 90)))
 for i, nm in enumerate(names):
-    a, b = h[:, i], h[:, i + 1]
-    ok = (a != 0) & (b != 0) & (b >= a)
-    d = (b - a)[ok]
+    a_, b_ = h[:, i], h[:, i + 1]
+    ok = (a_ != 0) & (b_ != 0) & (b_ >= a_)
+    d = (b_ - a_)[ok]
     if len(d):
-        print("  %-40s median %8.0f mean %8.0f  share %5.1f%%  (n=%d)" % (nm, np.median(d), d.mean(),
+        print("  %-50s median %8.0f mean %8.0f  share %5.1f%%  (n=%d)" % (nm, np.median(d), d.mean(),
                                                                          100 * d.sum() / tot.sum(), len(d)))
-rt = (h[:, 2] - h[:, 7])            # s_memrealtime ticks (100 MHz) over the tile
+rt = (h[:, 15] - h[:, 14])            # s_memrealtime ticks (100 MHz) over the tile
 ok = rt > 0
 print("in-kernel clock: %.2f GHz (median over tiles of d(s_memtime)/d(s_memrealtime) x 100 MHz)" %
-      (np.median((h[:, 6] - h[:, 0])[ok] / rt[ok]) * 0.1))
-t_first, t_last = h[:, 7].min(), h[:, 2].max()
+      (np.median((h[:, 8] - h[:, 0])[ok] / rt[ok]) * 0.1))
+t_first, t_last = h[:, 14].min(), h[:, 15].max()
 print("kernel span by s_memrealtime: %.1f us; sum of tile wave-times / span = %.2f waves per SIMD" %
       ((t_last - t_first) / 100.0, (rt[ok].sum() / (t_last - t_first)) / 1024.0))
-single = h[:, 2] - h[:, 1] < 200
-print("single-candidate tiles: %d; their adjoint rows median %.0f cycles" % (single.sum(), np.median((h[:, 4] - h[:, 3])[single])))
-# busy-wave profile over the kernel span (tiles in flight per SIMD): ramp-up, plateau, tail
-t0 = h[ok, 7] - t_first
-t1 = h[ok, 2] - t_first
+single = h[:, 3] - h[:, 2] < 200
+print("single-candidate tiles: %d; their adjoint rows median %.0f cycles, whole tile median %.0f" % (
+    single.sum(), np.median((h[:, 5] - h[:, 4])[single]), np.median(tot[single])))
+print("multi-candidate tiles: %d; winner search median %.0f, whole tile median %.0f" % (
+    (~single).sum(), np.median((h[:, 3] - h[:, 2])[~single]), np.median(tot[~single])))
+t0 = h[ok, 14] - t_first
+t1 = h[ok, 15] - t_first
 span = t_last - t_first
 nb = 24
 edges = np.linspace(0, span, nb + 1)
@@ -92,14 +99,13 @@ for i in range(nb):
     ov = np.clip(np.minimum(t1, hi) - np.maximum(t0, lo), 0, None).sum() / (hi - lo)
     prof.append(ov / 1024.0)
 print("busy waves per SIMD over %d slices of the span: %s" % (nb, " ".join("%.1f" % x for x in prof)))
-dur = (h[:, 2] - h[:, 7])[ok] / 100.0
+dur = (h[:, 15] - h[:, 14])[ok] / 100.0
 print("tile duration (us): median %.2f p10 %.2f p90 %.2f p99 %.2f max %.2f" % (
     np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
-# per-workgroup finish times (slot 5 = workgroup id of the tile's last adjoint pass)
-ok = ok & (h[:, 5] < 65536)
-wg = h[ok, 5].astype(np.int64)
-dur = (h[:, 2] - h[:, 7])[ok] / 100.0
-endt = (h[ok, 2] - t_first) / 100.0
+ok = ok & (h[:, 13] < 65536)
+wg = h[ok, 13].astype(np.int64)
+dur = (h[:, 15] - h[:, 14])[ok] / 100.0
+endt = (h[ok, 15] - t_first) / 100.0
 last = np.zeros(wg.max() + 1)
 np.maximum.at(last, wg, endt)
 cntw = np.bincount(wg, minlength=len(last))
