@@ -211,7 +211,8 @@ void harness_bwd(int use_double, int S, const float* w2o, const float* mat, cons
 // outside it.  Also reports the mean candidate count per tile.
 int64_t harness_cull_check(int S, const float* w2o, const float* mat, const float* light, const uint8_t* kind,
                            const float* cam, const HView* hvp, const float* jitter, int tw, int th,
-                           double* mean_candidates) {
+                           double* mean_candidates, int64_t* hist /* [4]: tiles with 0, 1, 2, 3+ candidates, or NULL */,
+                           int check_rays) {
   const HView& hv = *hvp;
   ViewK v = make_view<float>(hv);
   Packed<float> pk;
@@ -229,13 +230,17 @@ int64_t harness_cull_check(int S, const float* w2o, const float* mat, const floa
       Cone<float> cone = tile_cone<float>(v, i0, i1, j0, j1);
       Frustum<float> fr = tile_frustum<float>(v, i0, i1, j0, j1);
       std::vector<char> cand(S);
+      int ncand = 0;
       for (int k = 0; k < S; ++k) {
         const float* p = pk.ps.data() + (size_t)k * PS_STRIDE;
         cand[k] = cone_may_hit<float>(cone, p + PS_CULL_C, p[PS_CULL_R]) &&
                   frustum_may_hit<float>(fr, p + PS_CULL_C, p[PS_CULL_R]);
         cand_sum += cand[k];
+        ncand += cand[k];
       }
+      if (hist) ++hist[ncand > 3 ? 3 : ncand];
       ++tiles;
+      if (!check_rays) continue;
       for (int a = a0; a <= a1; ++a)
         for (int b = b0; b <= b1; ++b) {
           int i, j;

@@ -111,13 +111,15 @@ def bwd(w2o, material, light, kinds=None, *, grad_image, x_dims, y_dims, A=1, ca
 
 
 def cull_check(w2o, material, light, kinds=None, *, x_dims, y_dims, A=1, cam=None, transpose=True,
-               jitter=None, seed=0, row0=0, rows=None, tw=64, th=16):
+               jitter=None, seed=0, row0=0, rows=None, tw=64, th=16, want_hist=False, check_rays=True):
     w2o = _f32(np.asarray(w2o)[:, :3, :]); material = _f32(material); light = _f32(light)
     S = w2o.shape[0]
     kind = np.ascontiguousarray(np.asarray(kinds if kinds is not None else [0] * S, dtype=np.uint8))
     cam = _f32(cam if cam is not None else IDENT_CAM)
     hv, jit, rows, ncols = _view(x_dims, y_dims, A, transpose, "phong", True, 1.0, jitter, seed, row0, rows)
     mean = ctypes.c_double(0)
+    hist = np.zeros(4, dtype=np.int64)
     v = lib().harness_cull_check(S, _ptr(w2o), _ptr(material), _ptr(light), _ptr(kind, ctypes.c_uint8),
-                                 _ptr(cam), ctypes.byref(hv), _ptr(jit), tw, th, ctypes.byref(mean))
-    return int(v), mean.value
+                                 _ptr(cam), ctypes.byref(hv), _ptr(jit), tw, th, ctypes.byref(mean),
+                                 _ptr(hist, ctypes.c_int64), int(bool(check_rays)))
+    return (int(v), mean.value, hist) if want_hist else (int(v), mean.value)
