@@ -527,7 +527,8 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
   const T q = beta * ia;
   const T op[3] = {o[0] - q * r[0], o[1] - q * r[1], o[2] - q * r[2]};
   const T Dp = T(1) - (op[0] * op[0] + op[1] * op[1] + op[2] * op[2]);
-  if (!(Dp > T(0))) return false;                             // miss (or NaN) => exactly zero
+  // a miss (Dp <= 0) needs no test of its own: 1/sqrt of a non-positive number is NaN or infinite, h = x / sqrt(x)
+  // and with it phi become NaN, and the ONE test below drops the ray -- one exec-mask region per row instead of two
   const T x = Dp * ia;
   const T ih = m_rsqrt<T>(x);
   const T h = x * ih;
@@ -546,7 +547,8 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
     pw = p1 * s;
     phi += ks * pw;
   }
-  if (!(phi >= T(0))) return false;                           // all three channels clipped at 0 (or NaN)
+  // a miss, all three channels clipped at 0, or NaN: exactly zero
+  if (!(phi >= T(0)) || !(Dp > T(0))) return false;
   T um[3] = {up[0], up[1], up[2]};
   if (RRT_WAVE_ANY(phi * cmax > T(1))) {
     for (int c = 0; c < 3; ++c) um[c] = (phi * colI[c] <= T(1)) ? up[c] : T(0);

@@ -1018,9 +1018,13 @@ __device__ __forceinline__ void wave_sums_22(const float acc[ACC_USED], float r6
 // double buffer 128 KB.)
 constexpr int UP_ROW = 64 * 3;
 template <int P>
-__device__ __forceinline__ void prefetch_grad_rows(const KArgs& a, const Tile& t, int lane, float* dst) {
+__device__ __forceinline__ void prefetch_grad_rows(const KArgs& a, const Tile& t, int lane_unused, float* dst) {
   typedef const __attribute__((address_space(1))) void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
+  // the lane id straight from the hardware (two VALU ops): derived from threadIdx it stays live across the
+  // whole tile loop as a 64-bit address offset, and the register allocator spilled it in front of every load
+  (void)lane_unused;
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   // one address computation per tile, one add per row
   const size_t row_bytes = (size_t)a.v.ncols * 12;
   const char* row = reinterpret_cast<const char*>(a.grad) + ((size_t)t.b * a.v.rows + t.a0) * row_bytes + (size_t)t.b0 * 12;
@@ -1171,22 +1175,27 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
           asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
         }
         asm volatile("" : "+v"(shm1));
+        auto fast_row = [&](int p, int s, float jcx, float jcy) {
+          const bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
+          if (on) {
+            float d[3];
+            row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+            const float* ur = up_rows + p * UP_ROW + 3 * lane;
+            const float up[3] = {ur[0], ur[1], ur[2]};
+            const bool hit = adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh, q.powf,
+                                                               Lv, lookv, sc.Llook, d, up, acc);
+            if (MULTI) anyhit |= hit;
+          }
+        };
+        // single-candidate tiles do not track whether anything hit (a few per cent of them add zeros to the
+        // accumulators: cheaper than the mask bookkeeping in every row).  (Rows unrolled: spills in the tile loop.)
+        if (!MULTI) anyhit = true;
 #pragma unroll 1
         for (int s = s_lo; s < s_hi; ++s) {
           float jcx, jcy;
           centre_jitter(v, s, jcx, jcy);
 #pragma unroll 1
-          for (int p = 0; p < t.nrows; ++p) {
-            const bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
-            if (on) {
-              float d[3];
-              row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
-              const float* ur = up_rows + p * UP_ROW + 3 * lane;
-              const float up[3] = {ur[0], ur[1], ur[2]};
-              anyhit |= adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh, q.powf,
-                                                          Lv, lookv, sc.Llook, d, up, acc);
-            }
-          }
+          for (int p = 0; p < t.nrows; ++p) fast_row(p, s, jcx, jcy);
         }
       } else {
         shape_transform(qword, q);
