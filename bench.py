@@ -166,7 +166,7 @@ def cpu_baseline(size, spheres, aa, rows):
     """The CPU oracle (a float32 op-for-op restatement of the reference's Theano graph + autograd,
     array-at-a-time like the Theano graph) on a band of the same workload, timed on this host:
     once on the GPU box's core share (16 threads) and once on ONE thread (Theano's elementwise
-    loops are single-threaded without OpenMP, README.md:11) on a band an eighth as high.  The
+    loops are single-threaded without OpenMP, README.md:11) on a band a quarter as high.  The
     Mrays/s of a band is what the 4096-row image would run at (every row costs the same: the
     oracle shades every shape at every pixel); it is an extrapolation, and says so."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -187,7 +187,7 @@ def cpu_baseline(size, spheres, aa, rows):
     # the GPU box gives one GPU a 16-core share; torch's default (all 128 logical CPUs) only adds overhead
     threads = min(16, os.cpu_count() or 1)
     v_all, r0, nr, dt_all = run(rows, threads)
-    v_one, r1, n1, dt_one = run(max(16, rows // 8), 1)
+    v_one, r1, n1, dt_one = run(max(16, rows // 4), 1)
     torch.set_num_threads(threads)
     return {"value": v_all, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "rows [%d,%d) of the %dx%d/%d-sphere workload, fwd+bwd, float32 torch-CPU oracle, %.1f s; the figure "
@@ -218,14 +218,14 @@ def parity_sample(dev, size, spheres, aa, rows=48):
     (img * torch.tensor(G, dtype=torch.float32, device=dev)).sum().backward()
     torch.cuda.synchronize()
     oi, ow, om, ol = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, x_dims=size, y_dims=size,
-                                        antialias_samples=aa, row0=row0, rows=rows)
+                                        antialias_samples=aa, row0=row0, rows=rows, shininess_grad="masked")
     di = (img.detach().cpu().double() - oi).abs().amax(-1)
 
     def stats(a, b):
         d = (a.detach().cpu().double() - b).abs().max().item()
         return d, d / max(b.abs().max().item(), 1e-30)
     aw, rw = stats(tw.grad, ow)
-    am, rm = stats(tm.grad[:, :6], om[:, :6])
+    am, rm = stats(tm.grad, om)                     # all seven columns, d/dshininess included
     al, rl = stats(tl.grad, ol)
     return {"sample": "rows [%d,%d) of the workload, white-noise upstream gradient, vs the float64 CPU oracle"
                       % (row0, row0 + rows),
