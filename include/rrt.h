@@ -74,6 +74,12 @@ typedef enum rrt_status {
                                     re-dealing (backward right after its forward;
                                     repeated forwards of an unchanged scene) */
 
+#define RRT_FLAG_SHADOWS 8u       /* EXTENSION, default off, Phong shader only: hard shadows after the reference's dormant
+                                    Sphere.shadow (shape.py:85-97; its only call site, scene.py:41-45, is commented
+                                    out, so no render of the reference shows them).  The point a ray hits is black
+                                    when another Sphere lies between it and lights[0]; no gradient flows through
+                                    the (piecewise constant) shadow mask.  Squares receive shadows but cast none. */
+
 #define RRT_FLAG_SKIP_FINALIZE 4u /* rrt_render_bwd, measurement only: run the adjoint kernel but not the
                                     final chain to w2o/material/light (g_* are left untouched and the
                                     accumulators un-rewound: a normal rrt_render_bwd WITHOUT

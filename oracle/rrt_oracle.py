@@ -337,8 +337,18 @@ def depth_shade(kind, rays, origin, max_depth):
 def render(w2o, material, light, kinds=None, *, x_dims, y_dims,
            antialias_samples=4, shader="phong", specular=True, max_depth=1.0,
            cam_o2w=None, look_at=(0.0, 0.0, 1.0), sample_dist=None,
-           row0=0, rows=None, dtype=torch.float64, shininess_grad="theano"):
+           row0=0, rows=None, dtype=torch.float64, shininess_grad="theano", shadows=False):
     """scene.py:18-52 (``Scene.build``), orbit camera orbit_experiments/scene.py:56-80.
+
+    shadows=True is an EXTENSION with no reference behaviour to pin it (parity unpinned): the hard
+    shadows of the dormant ``Sphere.shadow`` (shape.py:85-97), whose only call site is commented out
+    (scene.py:41-45) and whose helper ``surface_pts`` raises NameError (shape.py:106).  The reading
+    implemented here and in the kernels: the point a ray hits on shape k, carried into the object space
+    of every OTHER Sphere k2 (y = o'_k2 + t r'_k2), is in shadow iff the ray from y towards the light
+    (direction w2o_k2 . (-Lhat)) enters k2's unit sphere ahead of it -- discriminant > 0 and the nearer
+    root >= 0, i.e. Sphere.shadow's ``-x - sqrt(decider) >= 0`` generalised to a non-unit direction;
+    a shadowed Phong shading becomes (0,0,0) (the commented-out ``broadcasted_switch``).  Squares
+    receive shadows but cast none (the reference defines no Square.shadow); Phong shader only.
 
     w2o        [S,4,4] (or [S,3,4]) world->object matrices (``shape.w2o.m``)
     material   [S,7]   r,g,b,ks,kd,ka,shininess
@@ -405,6 +415,20 @@ def render(w2o, material, light, kinds=None, *, x_dims, y_dims,
             if shader == "phong":
                 shadings = phong_shade(kinds[k], r_k, o_k, material[k], light, look,
                                        specular=specular, shininess_grad=shininess_grad)
+                if shadows:
+                    t_k = torch.where(torch.isinf(dists), torch.zeros_like(dists), dists).detach()
+                    Lhat = normed_dir(light[0:3]).detach()
+                    shadowed = torch.zeros_like(dists, dtype=torch.bool)
+                    for k2 in range(S):
+                        if k2 == k or kinds[k2] != SPHERE:
+                            continue
+                        o_2, r_2 = transform_apply(w2o[k2].detach(), origin, rays)
+                        y = o_2 + t_k[:, :, None] * r_2
+                        ell = w2o[k2][:3, :3].detach() @ (-Lhat)
+                        yl = torch.tensordot(y, ell, dims=1)
+                        disc = yl * yl - torch.dot(ell, ell) * (torch.sum(y * y, dim=2) - 1)
+                        shadowed = shadowed | ((disc > 0) & (yl < 0) & (torch.sum(y * y, dim=2) >= 1))
+                    shadings = torch.where(shadowed[:, :, None], torch.zeros_like(shadings), shadings)
             else:
                 shadings = depth_shade(kinds[k], r_k, o_k, max_depth)
             if image_per_sample is None:

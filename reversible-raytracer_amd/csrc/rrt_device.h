@@ -49,6 +49,8 @@ constexpr int PS_CMAX = 22;   //      max_j colI_j           (fast paths: one co
 constexpr int PS_KSSH = 23;   //      ks * shininess         (fast adjoint)
 constexpr int PS_CULL_C = 24; // [3]  centre of a bounding ball, camera-local
 constexpr int PS_CULL_R = 27; //      its radius (inf = never cull)
+constexpr int PS_ELL = 28;    // [3]  w2o_linear . (-Lhat): the direction towards the light in object space (shadows)
+constexpr int PS_ELL2 = 31;   //      its squared length
 
 // Per-scene header (one per batch element).
 constexpr int HDR_STRIDE = 32;
@@ -288,6 +290,26 @@ RRT_HD bool hit_square(const T r[3], const T o[3], T& t) {
   T x = m_fma(t, r[0], o[0]);
   T y = m_fma(t, r[1], o[1]);
   return np && (t > T(0)) && (x > T(-0.5)) && (x < T(0.5)) && (y > T(-0.5)) && (y < T(0.5));
+}
+
+// ---------------------------------------------------------------- shadows --
+// EXTENSION, default off (RRT_FLAG_SHADOWS), no reference behaviour to be identical to: the hard
+// shadows of the reference's dormant Sphere.shadow (shape.py:85-97; its call site scene.py:41-45 is
+// commented out).  The point a ray (camera-local direction d, distance t) hits, in the object space
+// of ANOTHER Sphere with packed A2, o2: y = o2 + t A2 d.  It is in that sphere's shadow iff the ray
+// from y towards the light, y + tau ell (ell = w2o_linear . (-Lhat), not unit in general), enters the
+// unit sphere ahead of it: discriminant (y.ell)^2 - |ell|^2 (|y|^2 - 1) > 0 and the nearer root
+// tau = (-(y.ell) - sqrt(disc)) / |ell|^2 >= 0  <=>  y.ell < 0 and |y| >= 1 (no square root needed).
+// For ell = -Lhat (a pure translation) this is Sphere.shadow's "-x - sqrt(decider) >= 0".
+template <class T>
+RRT_HD bool shadowed_by(const T* A2, const T o2[3], const T ell[3], T ell2, const T d[3], T t) {
+  T r2[3];
+  xform_dir<T>(A2, d, r2);
+  const T y[3] = {o2[0] + t * r2[0], o2[1] + t * r2[1], o2[2] + t * r2[2]};
+  const T yl = y[0] * ell[0] + y[1] * ell[1] + y[2] * ell[2];
+  const T yy = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+  const T disc = yl * yl - ell2 * (yy - T(1));
+  return disc > T(0) && yl < T(0) && yy >= T(1);
 }
 
 // --------------------------------------------------------------- shading --
@@ -778,7 +800,15 @@ RRT_HD void pack_shape(const float* w2o, const float* cam, const float* mat, con
   ps[PS_CULL_C + 1] = ok ? (ST)cc[1] : ST(0);
   ps[PS_CULL_C + 2] = ok ? (ST)cc[2] : ST(0);
   ps[PS_CULL_R] = ok ? (ST)R : (ST)INFINITY;
-  for (int q = 28; q < PS_STRIDE; ++q) ps[q] = ST(0);
+  {
+    // towards the light, in object space (shadows): w2o_linear . (-L / |L|)
+    const T L0 = T(light[0]), L1 = T(light[1]), L2 = T(light[2]);
+    const T il = T(-1) / sqrt(L0 * L0 + L1 * L1 + L2 * L2);
+    T e[3];
+    for (int r = 0; r < 3; ++r) e[r] = (A[3 * r] * L0 + A[3 * r + 1] * L1 + A[3 * r + 2] * L2) * il;
+    ps[PS_ELL] = (ST)e[0]; ps[PS_ELL + 1] = (ST)e[1]; ps[PS_ELL + 2] = (ST)e[2];
+    ps[PS_ELL2] = (ST)(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  }
 }
 
 template <class T, class ST>

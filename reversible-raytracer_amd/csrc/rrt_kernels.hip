@@ -301,6 +301,29 @@ __device__ __forceinline__ void stage_one_scene(const KArgs& a, float* lds, int 
   for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = src[i];
 }
 
+// EXTENSION (RRT_FLAG_SHADOWS, default off; rrt_device.h: shadowed_by): is the point this lane's ray hits
+// (camera-local direction d, distance t, on shape `self` -- may differ per lane) in the shadow of another
+// Sphere of scene b?  A shadow ray can leave the tile's candidate set, so all S shapes are visited; the
+// wave stops as soon as none of its lanes is both concerned and still lit -- the wave ballot is the
+// any-hit test.  Must be called by all lanes (`active` says which ones are concerned).
+__device__ __forceinline__ bool wave_in_shadow(const KArgs& a, const float* lds, int b, int self, const float d[3],
+                                               float t, bool active, int lane) {
+  bool sh = false;
+  for (int k2 = 0; k2 < a.S; ++k2) {
+    if (!__ballot(active && !sh)) break;
+    const float word = shape_word(a, lds, b, k2, lane);
+    if (ps_load_int(lane_bcast(word, PS_KIND)) != KIND_SPHERE) continue;     // only Spheres cast shadows
+    float A2[9], o2[3], ell[3];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) A2[n] = lane_bcast(word, PS_A + n);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) { o2[n] = lane_bcast(word, PS_O + n); ell[n] = lane_bcast(word, PS_ELL + n); }
+    const bool s2 = shadowed_by<float>(A2, o2, ell, lane_bcast(word, PS_ELL2), d, t);
+    sh |= active && k2 != self && s2;
+  }
+  return sh;
+}
+
 // Ray generation, split so that what depends only on the lane stays out of the row loops
 // (rrt_device.h: ray_dir_parts).  LaneRay: the lane's own grid coordinate cl (u under the root
 // camera's transpose, w otherwise), q = cl^2 + 1 and its clamped image column.
@@ -760,7 +783,7 @@ __device__ __forceinline__ void shade_hit(const KArgs& a, const ShapeP& q, const
 // tiles to zero-fill, so the store stream runs under the arithmetic and no wave idles
 // behind an unlucky static deal (a wave timeline -- tools/stamp_fwd.py -- showed a third of
 // a statically dealt wave's life in the list prologue and an 11 us tail).
-template <int P, int SHADER, int SPEC, int JC, int TR>
+template <int P, int SHADER, int SPEC, int JC, int TR, int SH>
 __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   __shared__ WgQueue s_q;
@@ -874,6 +897,11 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
           float Av[9], ov[3];
           load_shape_vgpr(a, s_scene, t.b, k0, Av, ov);
           trace_shape_p<P, SHADER == SHADER_PHONG>(q.kind, Av, ov, k0, d, best, tmin, nu);
+          if (SH) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              if (wave_in_shadow(a, s_scene, t.b, best[p], d[p], tmin[p], best[p] >= 0, lane)) best[p] = -1;   // black
+          }
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             if (best[p] >= 0) {
@@ -892,6 +920,11 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
               load_shape(a, s_scene, t.b, k, lane, q);
               trace_shape<P, SHADER == SHADER_PHONG>(q, k, d, best, tmin, nu);
             }
+          }
+          if (SH) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              if (wave_in_shadow(a, s_scene, t.b, best[p], d[p], tmin[p], best[p] >= 0, lane)) best[p] = -1;   // black
           }
           if (SHADER == SHADER_DEPTH) {
 #pragma unroll
@@ -1072,7 +1105,7 @@ struct BwdWave {
 // samples run INSIDE the accumulation, so the tile pays one butterfly.  A workgroup's queue is
 // ordered by cost class (3+ candidates, 2, 1), so a wave runs its MULTI tiles in one loop and its
 // single-candidate tiles in a second, leaner one (fewer live scalars: the general loop spills SGPRs).
-template <int P, int SHADER, int SPEC, int JC, int TR, bool MULTI>
+template <int P, int SHADER, int SPEC, int JC, int TR, bool MULTI, int SH>
 __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_q, unsigned cnt, const float* s_scene,
                                          float* s_acc, float* s_up_wave, int (*s_best_wave)[64], int lane) {
   const ViewK& v = a.v;
@@ -1162,7 +1195,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
       for (int n = 0; n < ACC_USED; ++n) { acc[n] = 0.f; asm volatile("" : "+v"(acc[n])); }
       bool anyhit = false;
       RRT_STAMP(4);
-      if (SHADER == SHADER_PHONG && (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC))) {
+      if (!SH && SHADER == SHADER_PHONG && (q.powf & (SPEC ? FAST_SPEC : FAST_NOSPEC))) {
         // the hot path: a FAST_* Sphere (rrt_device.h: adjoint_sphere_phong).  Its most used uniforms --
         // the transform, the light and view directions -- as per-lane VGPR copies: on gfx950 a VALU
         // instruction with an SGPR source issues at about half the rate of one that reads only VGPRs
@@ -1205,10 +1238,22 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
           centre_jitter(v, s, jcx, jcy);
 #pragma unroll 1
           for (int p = 0; p < t.nrows; ++p) {
-            const bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
-            if (on) {
-              float d[3];
+            bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
+            float d[3];
+            if (SH) {
+              // (extension) a shadowed hit is black: no gradient.  The distance of shape k along this ray, then the
+              // wave-wide any-hit walk over the other spheres -- every lane takes part, `on` says who is concerned
               row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
+              float r[3], tt = 0.f;
+              xform_dir<float>(q.A, d, r);
+              bool hit;
+              if (q.kind == KIND_SPHERE) { SphereHit<float> sp; hit = hit_sphere<float>(r, q.o, sp); tt = sp.t; }
+              else hit = hit_square<float>(r, q.o, tt);
+              on = on && hit;
+              if (wave_in_shadow(a, s_scene, t.b, k, d, tt, on, lane)) on = false;
+            }
+            if (on) {
+              if (!SH) row_ray<JC, TR>(a, lr, t.a0 + p, s, jcx, jcy, d);
               const float* ur = up_rows + p * UP_ROW + 3 * lane;
               const float up[3] = {ur[0], ur[1], ur[2]};
               anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
@@ -1267,7 +1312,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
 // the upstream gradient), pulled from the workgroup's LDS queue.  The next
 // tile's gradient rows are requested before the current tile is processed, so
 // HBM latency hides behind the adjoint.
-template <int P, int SHADER, int SPEC, int JC, int TR>
+template <int P, int SHADER, int SPEC, int JC, int TR, int SH>
 __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   __shared__ WgQueue s_q;
@@ -1366,11 +1411,11 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     }
     // the queue is ordered by cost class: first the tiles with several candidates, then the others
     while (w.has_cur && entry_is_multi(w.e_cur))
-      bwd_tile<P, SHADER, SPEC, JC, TR, true>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
+      bwd_tile<P, SHADER, SPEC, JC, TR, true, SH>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
     // (queue_fill stages a workgroup's share in list order -- class 0, 1, 2 -- and the saved batches keep
     // that order: no entry with several candidates follows one with a single candidate)
     while (w.has_cur)
-      bwd_tile<P, SHADER, SPEC, JC, TR, false>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
+      bwd_tile<P, SHADER, SPEC, JC, TR, false, SH>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
   }
   if (w.held && lane < ACC_USED)
     __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val, __ATOMIC_RELAXED,
@@ -1747,9 +1792,13 @@ int launch_prepare(const rrt_scene* s, const rrt_view* v, const KArgs& a, hipStr
 
 template <int P, int JC, int TR>
 void launch_fwd_jt(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
-  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0, 0, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  // (extension) hard shadows: their own instantiations, generic jitter code only -- the default kernels are untouched
+  const bool sh = (a.v.flags & RRT_FLAG_SHADOWS) != 0 && shader == SHADER_PHONG;
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_fwd<P, SHADER_DEPTH, 0, 0, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (sh && spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1, 0, TR, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (sh) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0, 0, TR, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 1, JC, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_fwd<P, SHADER_PHONG, 0, JC, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
 }
 // JC = 1: jitter at the stratum centre (the per-ray hash / explicit-jitter code drops out of the row
 // loops); TR = view.transpose (which grid coordinate runs along a wave's lanes)
@@ -1762,9 +1811,12 @@ void launch_fwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream
 
 template <int P, int JC, int TR>
 void launch_bwd_jt(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {
-  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0, 0, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0, JC, TR>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  const bool sh = (a.v.flags & RRT_FLAG_SHADOWS) != 0 && shader == SHADER_PHONG;
+  if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0, 0, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (sh && spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1, 0, TR, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (sh) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0, 0, TR, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1, JC, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0, JC, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
 }
 template <int P>
 void launch_bwd(const KArgs& a, unsigned blocks, int shader, int spec, hipStream_t st) {

@@ -22,7 +22,7 @@ MAX_SHAPES = 1024
 KIND_SPHERE, KIND_SQUARE = 0, 1
 SHADER_PHONG, SHADER_DEPTH = 0, 1
 JITTER_CENTER, JITTER_EXPLICIT, JITTER_HASH = 0, 1, 2
-FLAG_NO_CULL, FLAG_REUSE_SETUP, FLAG_SKIP_FINALIZE = 1, 2, 4
+FLAG_NO_CULL, FLAG_REUSE_SETUP, FLAG_SKIP_FINALIZE, FLAG_SHADOWS = 1, 2, 4, 8
 
 # every symbol include/rrt.h declares
 EXPORTS = ("rrt_version", "rrt_strerror", "rrt_last_hip_error", "rrt_image_cols",

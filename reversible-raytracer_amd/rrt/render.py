@@ -20,11 +20,11 @@ class RenderOptions(object):
     """Everything about a render that is not a differentiable tensor."""
 
     __slots__ = ("x_dims", "y_dims", "antialias_samples", "shader", "specular", "max_depth",
-                 "transpose", "jitter_mode", "seed", "row0", "rows", "cull")
+                 "transpose", "jitter_mode", "seed", "row0", "rows", "cull", "shadows")
 
     def __init__(self, x_dims, y_dims, antialias_samples=4, shader="phong", specular=True,
                  max_depth=1.0, transpose=True, jitter_mode=N.JITTER_CENTER, seed=0,
-                 row0=0, rows=None, cull=True):
+                 row0=0, rows=None, cull=True, shadows=False):
         self.x_dims = int(x_dims)
         self.y_dims = int(y_dims)
         self.antialias_samples = int(antialias_samples)
@@ -38,6 +38,7 @@ class RenderOptions(object):
         full = self.x_dims if self.transpose else self.y_dims
         self.rows = full - self.row0 if rows is None else int(rows)
         self.cull = bool(cull)
+        self.shadows = bool(shadows)     # extension (RRT_FLAG_SHADOWS): not something the reference renders
 
     @property
     def ncols(self):
@@ -85,7 +86,8 @@ def _structs(w2o, material, light, cam, kinds, jitter, opts, flags, cull=None):
     vw.transpose = int(opts.transpose)
     vw.jitter_mode = opts.jitter_mode
     vw.seed = opts.seed
-    vw.flags = flags | (0 if (opts.cull if cull is None else cull) else N.FLAG_NO_CULL)
+    vw.flags = flags | (0 if (opts.cull if cull is None else cull) else N.FLAG_NO_CULL) | \
+        (N.FLAG_SHADOWS if opts.shadows else 0)
     vw.max_depth = opts.max_depth
     vw.cam = _ptr(cam).value
     vw.cam_bstride = 16 if (cam.dim() == 2 and cam.shape[0] > 1) else 0
@@ -212,14 +214,17 @@ def default_cam(device):
 
 def render(w2o, material, light, kinds=None, cam=None, *, x_dims, y_dims, antialias_samples=4,
            shader="phong", specular=True, max_depth=1.0, transpose=None, jitter=None,
-           row0=0, rows=None, cull=True):
+           row0=0, rows=None, cull=True, shadows=False):
     """Functional form of ``Scene(...).build(antialias_samples)``.
 
     jitter: None or "center" (U = 0.5), an int (hash seed: a reproducible
     stand-in for scene.py:24-25's unseeded draws) or a [y_dims,x_dims,A,2]
     tensor of sampleDist_x/_y (the reference's values (U + sample) / A lie in
     [0, 1]; a tensor with values outside that range is rendered without the
-    tile cull, whose bounds assume it).  ``transpose`` defaults to the root-camera
+    tile cull, whose bounds assume it).  ``shadows=True`` is an extension the
+    reference never renders (its ``Sphere.shadow`` is dormant, shape.py:85-97):
+    a Phong-shaded point is black when another Sphere lies between it and the
+    light; no gradient flows through the shadow mask.  ``transpose`` defaults to the root-camera
     semantics when ``cam`` is None and to the orbit semantics otherwise.
     """
     dev = w2o.device
@@ -241,5 +246,5 @@ def render(w2o, material, light, kinds=None, cam=None, *, x_dims, y_dims, antial
     if kinds is not None and not torch.is_tensor(kinds):
         kinds = torch.as_tensor(np.asarray(kinds, dtype=np.uint8), device=dev)
     opts = RenderOptions(x_dims, y_dims, antialias_samples, shader, specular, max_depth, transpose,
-                         mode, seed, row0, rows, cull)
+                         mode, seed, row0, rows, cull, shadows)
     return RenderFn.apply(w2o, material, light, cam, kinds, jit_t, opts)

@@ -51,7 +51,7 @@ class Scene(object):
         light = self.lights[0].as_row()        # only lights[0] is used (shader.py:33)
         return w2o, material, light, kinds, self.camera.as_row()
 
-    def build(self, antialias_samples=4, jitter=None, row0=0, rows=None):
+    def build(self, antialias_samples=4, jitter=None, row0=0, rows=None, shadows=False):
         """scene.py:18-52 -> image tensor (x_dims, y_dims, 3), attached to autograd.
 
         jitter: None -> the reference draws unseeded uniform jitter once, at
@@ -63,6 +63,8 @@ class Scene(object):
         (values in [0, 1] like the reference's (U + sample) / A; anything else is
         rendered with the tile cull off, see rrt.render).
         ``row0/rows`` render a band of image rows (multi-GPU sharding).
+        ``shadows=True``: hard shadows after the dormant ``Sphere.shadow`` (shape.py:85-97; the reference's
+        own call site, scene.py:41-45, is commented out) -- an extension, off by default.
         """
         cam = self.camera
         jit_t = None
@@ -81,7 +83,7 @@ class Scene(object):
             jit_t = torch.as_tensor(jitter, dtype=floatX, device=device())
         opts = RenderOptions(cam.x_dims, cam.y_dims, antialias_samples, self.shader.shader_id,
                              getattr(self.shader, "specular", True), getattr(self.shader, "maxDepth", 1.0),
-                             cam.transpose, mode, seed, row0, rows)
+                             cam.transpose, mode, seed, row0, rows, True, shadows)
         w2o, material, light, kinds, cam_row = self.pack()
         return RenderFn.apply(w2o, material, light, cam_row, kinds, jit_t, opts)
 

@@ -26,7 +26,22 @@ struct HView {
   uint32_t seed;
   float max_depth;
   int32_t force_generic;   // 1: always shade_phong / adjoint_ray, never the FAST_* code paths
+  int32_t shadows;         // 1: RRT_FLAG_SHADOWS (extension)
 };
+
+// is the point the ray (d, t) hits on shape `self` in the shadow of another Sphere?
+template <class T>
+bool in_shadow(const T* ps, int S, int self, const T d[3], T t) {
+  for (int k2 = 0; k2 < S; ++k2) {
+    const T* p = ps + (size_t)k2 * PS_STRIDE;
+    if (k2 == self || ps_load_int(p[PS_KIND]) != KIND_SPHERE) continue;
+    T A[9], o[3], ell[3];
+    for (int q = 0; q < 9; ++q) A[q] = T(p[PS_A + q]);
+    for (int q = 0; q < 3; ++q) { o[q] = T(p[PS_O + q]); ell[q] = T(p[PS_ELL + q]); }
+    if (shadowed_by<T>(A, o, ell, T(p[PS_ELL2]), d, t)) return true;
+  }
+  return false;
+}
 
 template <class T>
 ViewT<T> make_view(const HView& h) {
@@ -107,6 +122,7 @@ void fwd(int S, const float* w2o, const float* mat, const float* light, const ui
         int id = trace<T>(v, pk.ps.data(), S, d, h);
         if (ids) ids[((size_t)s * v.rows + a) * v.ncols + b] = id;
         if (id < 0) continue;
+        if (hv.shadows && v.shader == SHADER_PHONG && in_shadow<T>(pk.ps.data(), S, id, d, h.t)) continue;   // black
         const T* p = pk.ps.data() + (size_t)id * PS_STRIDE;
         T c[3];
         if (v.shader == SHADER_DEPTH) {
@@ -155,6 +171,7 @@ void bwd(int S, const float* w2o, const float* mat, const float* light, const ui
         Hit<T> h;
         int id = trace<T>(v, pk.ps.data(), S, d, h);
         if (id < 0) continue;
+        if (hv.shadows && v.shader == SHADER_PHONG && in_shadow<T>(pk.ps.data(), S, id, d, h.t)) continue;   // no gradient
         const T* p = pk.ps.data() + (size_t)id * PS_STRIDE;
         T A[9], o[3], colI[3];
         for (int q = 0; q < 9; ++q) A[q] = T(p[PS_A + q]);

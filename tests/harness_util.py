@@ -18,7 +18,8 @@ class HView(ctypes.Structure):
                 ("row0", ctypes.c_int32), ("rows", ctypes.c_int32), ("shader", ctypes.c_int32),
                 ("specular", ctypes.c_int32), ("transpose", ctypes.c_int32),
                 ("jitter_mode", ctypes.c_int32), ("seed", ctypes.c_uint32),
-                ("max_depth", ctypes.c_float), ("force_generic", ctypes.c_int32)]
+                ("max_depth", ctypes.c_float), ("force_generic", ctypes.c_int32),
+                ("shadows", ctypes.c_int32)]
 
 
 _lib = None
@@ -57,7 +58,8 @@ def make_cam(cam_o2w=None, look_at=(0, 0, 1)):
     return cam
 
 
-def _view(x_dims, y_dims, A, transpose, shader, specular, max_depth, jitter, seed, row0, rows, force_generic=False):
+def _view(x_dims, y_dims, A, transpose, shader, specular, max_depth, jitter, seed, row0, rows, force_generic=False,
+          shadows=False):
     n_full = x_dims if transpose else y_dims
     if rows is None:
         rows = n_full - row0
@@ -68,7 +70,7 @@ def _view(x_dims, y_dims, A, transpose, shader, specular, max_depth, jitter, see
     else:
         mode = 1
     hv = HView(x_dims, y_dims, A, row0, rows, 0 if shader == "phong" else 1, int(bool(specular)),
-               int(bool(transpose)), mode, seed, float(max_depth), int(bool(force_generic)))
+               int(bool(transpose)), mode, seed, float(max_depth), int(bool(force_generic)), int(bool(shadows)))
     jit = _f32(jitter) if mode == 1 else None
     ncols = y_dims if transpose else x_dims
     return hv, jit, rows, ncols
@@ -76,14 +78,14 @@ def _view(x_dims, y_dims, A, transpose, shader, specular, max_depth, jitter, see
 
 def fwd(w2o, material, light, kinds=None, *, x_dims, y_dims, A=1, cam=None, transpose=True,
         shader="phong", specular=True, max_depth=1.0, jitter=None, seed=0, row0=0, rows=None,
-        double=True, want_ids=False, force_generic=False):
+        double=True, want_ids=False, force_generic=False, shadows=False):
     """jitter: None (centre), int (hash seed) or [y,x,A,2] sampleDist array."""
     w2o = _f32(np.asarray(w2o)[:, :3, :]); material = _f32(material); light = _f32(light)
     S = w2o.shape[0]
     kind = np.ascontiguousarray(np.asarray(kinds if kinds is not None else [0] * S, dtype=np.uint8))
     cam = _f32(cam if cam is not None else IDENT_CAM)
     hv, jit, rows, ncols = _view(x_dims, y_dims, A, transpose, shader, specular, max_depth, jitter, seed, row0, rows,
-                                 force_generic)
+                                 force_generic, shadows)
     image = np.zeros((rows, ncols, 3), dtype=np.float64)
     ids = np.zeros((A, rows, ncols), dtype=np.int32) if want_ids else None
     lib().harness_fwd(int(double), S, _ptr(w2o), _ptr(material), _ptr(light), _ptr(kind, ctypes.c_uint8),
@@ -94,13 +96,13 @@ def fwd(w2o, material, light, kinds=None, *, x_dims, y_dims, A=1, cam=None, tran
 
 def bwd(w2o, material, light, kinds=None, *, grad_image, x_dims, y_dims, A=1, cam=None, transpose=True,
         shader="phong", specular=True, max_depth=1.0, jitter=None, seed=0, row0=0, rows=None, double=True,
-        force_generic=False):
+        force_generic=False, shadows=False):
     w2o = _f32(np.asarray(w2o)[:, :3, :]); material = _f32(material); light = _f32(light)
     S = w2o.shape[0]
     kind = np.ascontiguousarray(np.asarray(kinds if kinds is not None else [0] * S, dtype=np.uint8))
     cam = _f32(cam if cam is not None else IDENT_CAM)
     hv, jit, rows, ncols = _view(x_dims, y_dims, A, transpose, shader, specular, max_depth, jitter, seed, row0, rows,
-                                 force_generic)
+                                 force_generic, shadows)
     g = np.ascontiguousarray(np.asarray(grad_image, dtype=np.float64))
     assert g.shape == (rows, ncols, 3)
     gw = np.zeros((S, 3, 4)); gm = np.zeros((S, 7)); gl = np.zeros(6)

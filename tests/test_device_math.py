@@ -204,3 +204,59 @@ def test_fast_path_flags():
             hw, hm, hl = H.bwd(w2o, m, light, kinds, grad_image=G, x_dims=n, y_dims=n, A=1, double=True)
             for a, b in ((hw, ow), (hm, om), (hl, ol)):
                 assert np.abs(a - b.numpy()).max() <= 1e-8 * max(np.abs(b.numpy()).max(), 1e-30)
+
+
+def _shadow_scene():
+    """a big sphere with a small one between it and the light, a third one to the side, and a Square behind:
+    the small sphere's shadow falls on the big one (about 10 % of its lit pixels), the Square receives
+    shadows and casts none"""
+    w2o = np.stack([syn._w2o_translate_scale((0.0, 0.0, 6.0), 1.5), syn._w2o_translate_scale((-0.9, -0.9, 4.2), 0.5),
+                    syn._w2o_translate_scale((1.4, 0.3, 5.0), 0.4),
+                    O.compose(O.translate((0.3, -0.2, 9.0)), O.scale((7.0, 7.0, 1.0)))[1].numpy()[:3]]).astype(np.float32)
+    mat = np.array([[.8, .7, .6, .3, .7, .4, 20.], [.2, .8, .9, .2, .8, .3, 10.], [.9, .3, .3, .3, .6, .4, 50.],
+                    [.5, .5, .8, .0, .6, .5, 1.]], np.float32)
+    light = np.array([1., 1., 1.5, 1., .9, .8], np.float32)
+    return w2o, mat, light, np.array([0, 0, 0, 1], np.uint8)
+
+
+def test_shadows_extension_device_math_vs_oracle():
+    """RRT_FLAG_SHADOWS (an extension: the reference's Sphere.shadow is dormant, shape.py:85-97, so nothing pins
+    it): the product's shadowed_by + pack (object-space light direction) against the oracle's statement of the
+    same reading, float64, image and all gradients; the shadow actually changes the picture"""
+    w2o, mat, light, kinds = _shadow_scene()
+    n, A = 64, 2
+    G = np.random.RandomState(0).randn(n, n, 3)
+    sd = O.sample_dist_from_uniform(O.hash_u01(5, n, n, A))
+    kw = dict(x_dims=n, y_dims=n, antialias_samples=A, sample_dist=sd, shininess_grad="masked")
+    plain = O.render(w2o, mat, light, list(kinds), **{k: v for k, v in kw.items() if k != "shininess_grad"})
+    oi, ow, om, ol = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, shadows=True, **kw)
+    changed = (plain != oi).any(-1)
+    assert 40 < int(changed.sum()) < 0.5 * n * n
+    hi = H.fwd(w2o, mat, light, kinds, x_dims=n, y_dims=n, A=A, jitter=5, double=True, shadows=True)
+    assert np.abs(hi - oi.numpy()).max() < 1e-10
+    hw, hm, hl = H.bwd(w2o, mat, light, kinds, grad_image=G, x_dims=n, y_dims=n, A=A, jitter=5, double=True, shadows=True)
+    for a, b in ((hw, ow), (hm, om), (hl, ol)):
+        assert np.abs(a - b.numpy()).max() <= 1e-8 * max(np.abs(b.numpy()).max(), 1e-30)
+    # shadows off: the flag changes nothing
+    h0 = H.fwd(w2o, mat, light, kinds, x_dims=n, y_dims=n, A=A, jitter=5, double=True)
+    assert np.abs(h0 - plain.numpy()).max() < 1e-10
+
+
+def test_shadows_extension_gradient_finite_differences():
+    """the shadow mask is piecewise constant, so away from mask flips the gradient of the shadowed render is the
+    gradient of the lit pixels: central differences of the oracle's shadowed forward w.r.t. the material (a smooth
+    dependence: no geometry moves, no pixel changes its mask) equal its autograd and the product's adjoint"""
+    w2o, mat, light, kinds = _shadow_scene()
+    n = 48
+    G = np.random.RandomState(3).randn(n, n, 3)
+    kw = dict(x_dims=n, y_dims=n, antialias_samples=1)
+    oi, ow, om, ol = O.render_and_grads(w2o, mat, light, list(kinds), grad_image=G, shadows=True, shininess_grad="masked", **kw)
+
+    def f(m):
+        im = O.render(w2o, m, torch.tensor(light, dtype=torch.float64), list(kinds), shadows=True, **kw)
+        return (im * torch.tensor(G)).sum()
+    fd = O.finite_difference_grad(f, torch.tensor(mat, dtype=torch.float64), eps=1e-6).numpy()
+    cols = [0, 1, 2, 3, 4, 5]                                          # (shininess: integer exponents, pow's sign rule changes off them)
+    assert np.abs(fd[:, cols] - om.numpy()[:, cols]).max() <= 1e-6 * np.abs(fd[:, cols]).max()
+    hw, hm, hl = H.bwd(w2o, mat, light, kinds, grad_image=G, x_dims=n, y_dims=n, A=1, double=True, shadows=True)
+    assert np.abs(hm[:, cols] - fd[:, cols]).max() <= 1e-6 * np.abs(fd[:, cols]).max()

@@ -91,7 +91,8 @@ def hip_render(dev, w2o, mat, light, kinds, grad=None, **kw):
 
 
 def oracle(w2o, mat, light, kinds, grad, *, x_dims, y_dims, antialias_samples, jitter=None, cam=None,
-           shader="phong", specular=True, max_depth=1.0, row0=0, rows=None, dtype=torch.float64, want_flips=False):
+           shader="phong", specular=True, max_depth=1.0, row0=0, rows=None, dtype=torch.float64, want_flips=False,
+           shadows=False):
     sd = None
     if isinstance(jitter, (int, np.integer)):
         sd = O.sample_dist_from_uniform(O.hash_u01(jitter, y_dims, x_dims, antialias_samples))
@@ -102,7 +103,8 @@ def oracle(w2o, mat, light, kinds, grad, *, x_dims, y_dims, antialias_samples, j
         cam_o2w = np.eye(4)
         cam_o2w[:3, :4] = np.asarray(cam[:12]).reshape(3, 4)
     kw = dict(x_dims=x_dims, y_dims=y_dims, antialias_samples=antialias_samples, shader=shader, specular=specular,
-              max_depth=max_depth, cam_o2w=cam_o2w, sample_dist=sd, row0=row0, rows=rows, shininess_grad="masked")
+              max_depth=max_depth, cam_o2w=cam_o2w, sample_dist=sd, row0=row0, rows=rows, shininess_grad="masked",
+              shadows=shadows)
     kl = list(kinds) if kinds is not None else None
     img, gw, gm, gl = O.render_and_grads(w2o, mat, light, kl, grad_image=grad, dtype=dtype, **kw)
     if want_flips:
@@ -275,6 +277,29 @@ def test_explicit_jitter_outside_unit_range(dev):
     n, A = 80, 2
     sd = (np.random.RandomState(7).rand(n, n, A, 2) * 24.0 - 12.0).astype(np.float32)    # up to 12 pixels either way
     check_scene(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=A, jitter=sd)
+
+
+@pytest.mark.parametrize("n,A,specular,tile_rows", [(224, 2, True, 0), (96, 1, False, 0), (300, 1, True, 4), (176, 2, True, 2)])
+def test_shadows_extension(dev, n, A, specular, tile_rows, monkeypatch):
+    """RRT_FLAG_SHADOWS -- an extension with no reference behaviour behind it (the reference's Sphere.shadow is
+    dormant, shape.py:85-97; parity unpinned): the kernels' wave-ballot any-hit walk against the oracle's statement
+    of the same reading, image and gradients; multi- and single-candidate tiles, 1-, 2- and 4-row tiles"""
+    from rrt import _native
+    from test_device_math import _shadow_scene
+    w2o, mat, light, kinds = _shadow_scene()
+    if tile_rows:
+        monkeypatch.setenv("RRT_TUNE_P", str(tile_rows))
+        _native.lib().rrt_debug_reload_tuning()
+    try:
+        img = check_scene(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=A, jitter=13,
+                          specular=specular, shadows=True)
+        lit = hip_render(dev, w2o, mat, light, kinds, x_dims=n, y_dims=n, antialias_samples=A, jitter=13, specular=specular)
+    finally:
+        if tile_rows:
+            monkeypatch.delenv("RRT_TUNE_P")
+            _native.lib().rrt_debug_reload_tuning()
+    dark = ((img == 0).all(-1) & (lit > 0).any(-1)).sum()
+    assert dark > 0.003 * n * n                                    # the shadow is there
 
 
 def test_ellipsoid_rotate_scale(dev):

@@ -241,3 +241,32 @@ def test_batched_front_end_matches_transform_objects():
     assert g.shape == (5, 3) and torch.isfinite(g).all()
     m = batched.materials(rs.rand(5, 3), 0.3, torch.full((5,), 0.7), 0.5, 50.)
     assert m.shape == (5, 7) and torch.allclose(m[:, 3], torch.full((5,), 0.3)) and float(m[0, 6]) == 50.
+
+
+def test_mgd_auto_optimizer_sgd_step():
+    """MGDAutoOptimizer (optimize.py:63-84; orbit fork optimize.py:68-97): plain SGD over ae.params, the orbit
+    fork's 0.1 x learning rate for 1-D parameters when `lam` is given, stereo pairs unpacked into ae.cost"""
+    from rrt import MGDAutoOptimizer
+
+    class TinyAE(object):
+        def __init__(self):
+            self.W = torch.ones(2, 2, requires_grad=True)
+            self.b = torch.zeros(2, requires_grad=True)
+            self.params = [self.W, self.b]
+
+        def cost(self, X, Y=None):
+            out = X @ self.W + self.b
+            return ((out - (X if Y is None else Y)) ** 2).sum()
+
+    X = torch.tensor([[1.0, 2.0]])
+    ae = TinyAE()
+    c0 = MGDAutoOptimizer(ae).optimize([X])(0.01)
+    out = X @ torch.ones(2, 2)
+    gW = X.t() @ (2 * (out - X))
+    assert c0 == pytest.approx(float(((out - X) ** 2).sum()))
+    assert torch.allclose(ae.W.detach(), torch.ones(2, 2) - 0.01 * gW)
+    assert torch.allclose(ae.b.detach(), -0.01 * 2 * (out - X)[0])
+    ae2 = TinyAE()
+    MGDAutoOptimizer(ae2).optimize([(X, 2 * X)], lam=0.5)(0.01)            # stereo pair, 1-D params at 0.1 x lr
+    assert torch.allclose(ae2.W.detach(), torch.ones(2, 2) - 0.01 * (X.t() @ (2 * (out - 2 * X))))
+    assert torch.allclose(ae2.b.detach(), -0.001 * 2 * (out - 2 * X)[0])
