@@ -536,11 +536,12 @@ RRT_HD bool adjoint_ray(int kind, const T* A, const T o[3],
 //     special cases; non-integer shininess with s < 0 gives NaN like pow());
 //   * g_n = c1 look - g_dd Lhat and G_Lhat = g_s look - g_dd n straight from scalars.
 // kssh = ks * shininess, shm1 = shininess - 1, Llook = Lhat . look_at, cmax = max_j colI_j.
-// Returns whether the ray contributed.
+// *gs_sum collects sum g_s: the caller adds gs_sum * look_at to acc[ACC_LHAT..] when its rows are done
+// (adjoint_sphere_phong_finish).  Returns whether the ray contributed.
 template <class T, int SPEC>
 RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cmax, T ks, T kd, T ka, T shm1, T kssh,
                                  int powf, const T L[3], const T look[3], T Llook, const T d[3], const T up[3],
-                                 T* acc) {
+                                 T* acc, T* gs_sum) {
   T r[3];
   xform_dir<T>(A, d, r);
   const T alpha = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -548,16 +549,17 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
   const T ia = m_rcp<T>(alpha);
   const T q = beta * ia;
   const T op[3] = {o[0] - q * r[0], o[1] - q * r[1], o[2] - q * r[2]};
-  const T Dp = T(1) - (op[0] * op[0] + op[1] * op[1] + op[2] * op[2]);
+  const T Dp = m_fma(-op[2], op[2], m_fma(-op[1], op[1], m_fma(-op[0], op[0], T(1))));
   // a miss (Dp <= 0) needs no test of its own: 1/sqrt of a non-positive number is NaN or infinite, h = x / sqrt(x)
   // and with it phi become NaN, and the ONE test below drops the ray -- one exec-mask region per row instead of two
   const T x = Dp * ia;
   const T ih = m_rsqrt<T>(x);
   const T h = x * ih;
   const T t = -q - h;
-  const T nu[3] = {op[0] - h * r[0], op[1] - h * r[1], op[2] - h * r[2]};
-  const T inv = m_rsqrt<T>(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]);
-  const T n[3] = {nu[0] * inv, nu[1] * inv, nu[2] * inv};
+  // The hit point p = o' + t r' = o_perp - h r' lies ON the unit sphere -- t is the root of |o' + t r'| = 1 -- so the
+  // reference's normals p / |p| (shape.py:137) divide by exactly 1: the adjoint uses n = p and |p| = 1 (float32 puts |p|
+  // within ~1e-5 of 1; the forward image keeps the division).  Saves a reciprocal square root and nine multiplies a row.
+  const T n[3] = {op[0] - h * r[0], op[1] - h * r[1], op[2] - h * r[2]};
   const T ndl = n[0] * L[0] + n[1] * L[1] + n[2] * L[2];      // dd = -ndl
   T phi = ka - kd * ndl;
   T nlk = T(0), s = T(0), p1 = T(0), pw = T(0), l2 = T(0);
@@ -582,7 +584,7 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
   acc[ACC_KA] += g_phi;
   acc[ACC_KD] -= g_phi * ndl;
   T g_dd = g_phi * kd;
-  T g_n[3];
+  T g_n[3], ndg;
   if (SPEC) {
     acc[ACC_KS] += g_phi * pw;
     // d/dshininess = pw ln(s), lanes with s <= 0 contribute 0 (extension, see rrt.h)
@@ -594,17 +596,19 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
     const T c1 = -ndl * g_s2;                                 // g_n = 2 dd g_rm - g_dd Lhat
     for (int c = 0; c < 3; ++c) {
       g_n[c] = c1 * look[c] - g_dd * L[c];
-      acc[ACC_LHAT + c] += g_s * look[c] - g_dd * n[c];       // G_Lhat += g_rm - g_dd n
-    }
+      acc[ACC_LHAT + c] -= g_dd * n[c];                       // G_Lhat += g_rm - g_dd n; the g_rm = g_s look part is summed as a
+    }                                                         // scalar (gs_sum) and applied once per tile by the caller
+    *gs_sum += g_s;
+    ndg = c1 * nlk - g_dd * ndl;                              // n . g_n from the scalars at hand
   } else {
     for (int c = 0; c < 3; ++c) {
       g_n[c] = -g_dd * L[c];
       acc[ACC_LHAT + c] -= g_dd * n[c];
     }
+    ndg = -g_dd * ndl;
   }
-  // n = p/|p|
-  const T ndg = n[0] * g_n[0] + n[1] * g_n[1] + n[2] * g_n[2];
-  const T g_p[3] = {(g_n[0] - n[0] * ndg) * inv, (g_n[1] - n[1] * ndg) * inv, (g_n[2] - n[2] * ndg) * inv};
+  // n = p/|p|, |p| = 1
+  const T g_p[3] = {g_n[0] - n[0] * ndg, g_n[1] - n[1] * ndg, g_n[2] - n[2] * ndg};      // (I - n n^T) g_n
   const T g_t = g_p[0] * r[0] + g_p[1] * r[1] + g_p[2] * r[2];
   // t = t(r', o'), collected as in adjoint_ray (only well conditioned quantities appear)
   const T gta = g_t * ia;
@@ -621,6 +625,11 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
     acc[ACC_O + c] += g_o;
   }
   return true;
+}
+
+template <class T>
+RRT_HD void adjoint_sphere_phong_finish(T gs_sum, const T look[3], T* acc) {
+  for (int c = 0; c < 3; ++c) acc[ACC_LHAT + c] += gs_sum * look[c];
 }
 
 // Which of the two a (shape, view) pair takes; the kernels and the CPU harness both dispatch on it.

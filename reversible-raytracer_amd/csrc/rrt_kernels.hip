@@ -1208,6 +1208,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
           asm volatile("" : "+v"(Lv[n]), "+v"(lookv[n]));
         }
         asm volatile("" : "+v"(shm1));
+        float gs_sum = 0.f;                          // sum of g_s over the rows: G_Lhat's g_s look_at part, applied once below
         auto fast_row = [&](int p, int s, float jcx, float jcy) {
           const bool on = MULTI ? (s_best_wave[p][lane] == k) : col_ok;
           if (on) {
@@ -1216,7 +1217,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
             const float* ur = up_rows + p * UP_ROW + 3 * lane;
             const float up[3] = {ur[0], ur[1], ur[2]};
             const bool hit = adjoint_sphere_phong<float, SPEC>(Av, ov, q.colI, q.cmax, q.ks, q.kd, q.ka, shm1, q.kssh, q.powf,
-                                                               Lv, lookv, sc.Llook, d, up, acc);
+                                                               Lv, lookv, sc.Llook, d, up, acc, &gs_sum);
             if (MULTI) anyhit |= hit;
           }
         };
@@ -1230,6 +1231,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
 #pragma unroll 1
           for (int p = 0; p < t.nrows; ++p) fast_row(p, s, jcx, jcy);
         }
+        adjoint_sphere_phong_finish<float>(gs_sum, lookv, acc);
       } else {
         shape_transform(qword, q);
 #pragma unroll 1

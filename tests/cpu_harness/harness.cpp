@@ -179,12 +179,14 @@ void bwd(int S, const float* w2o, const float* mat, const float* light, const ui
         const int kindk = as_int(p[PS_KIND]), powf = as_int(p[PS_POWF]);
         T* ak = acc.data() + (size_t)id * ACC_STRIDE;
         if (!hv.force_generic && adjoint_is_fast(kindk, powf, v.shader, v.specular)) {
+          T gs = T(0);
           if (v.specular)
             adjoint_sphere_phong<T, 1>(A, o, colI, T(p[PS_CMAX]), T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]) - T(1),
-                                       T(p[PS_KSSH]), powf, L, look, T(pk.hdr[HDR_LLOOK]), d, up, ak);
+                                       T(p[PS_KSSH]), powf, L, look, T(pk.hdr[HDR_LLOOK]), d, up, ak, &gs);
           else
             adjoint_sphere_phong<T, 0>(A, o, colI, T(p[PS_CMAX]), T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]) - T(1),
-                                       T(p[PS_KSSH]), powf, L, look, T(pk.hdr[HDR_LLOOK]), d, up, ak);
+                                       T(p[PS_KSSH]), powf, L, look, T(pk.hdr[HDR_LLOOK]), d, up, ak, &gs);
+          adjoint_sphere_phong_finish<T>(gs, look, ak);      // (the kernels do this once per tile and shape)
         } else {
           adjoint_ray<T>(kindk, A, o, colI, T(p[PS_KS]), T(p[PS_KD]), T(p[PS_KA]), T(p[PS_SH]), powf, v.shader,
                          v.specular, T(v.inv_max_depth), L, look, d, up, ak);

@@ -217,6 +217,31 @@ def test_c3_match_mirror_1024_band(dev):
     check_scene(dev, w2o, mat, light, kinds, x_dims=1024, y_dims=1024, antialias_samples=1, row0=400, rows=48)
 
 
+def test_c3_match_mirror_1024_full(dev):
+    """BASELINE config 3 at its stated size: the match_mirror.py scene (2 spheres + Square), 1024 x 1024,
+    antialias_samples = 4, ONE launch on the GPU; the oracle covers the whole image in eight 128-row bands
+    (its array-at-a-time autograd would need tens of GB at once) whose gradients add up"""
+    from rrt import synthetic
+    w2o, mat, light, kinds = synthetic.match_mirror(True)
+    n, A, nb = 1024, 4, 8
+    G = np.random.RandomState(3).randn(n, n, 3)
+    hi, hw, hm, hl = hip_render(dev, w2o, mat, light, kinds, grad=G, x_dims=n, y_dims=n, antialias_samples=A, jitter=5)
+    gw, gm, gl = np.zeros_like(hw), np.zeros_like(hm), np.zeros_like(hl)
+    fw, fm, fl = np.zeros_like(hw), np.zeros_like(hm), np.zeros_like(hl)
+    flips = 0
+    for b in range(nb):
+        r0, nr = b * (n // nb), n // nb
+        kw = dict(x_dims=n, y_dims=n, antialias_samples=A, jitter=5, row0=r0, rows=nr)
+        oi, ow, om, ol = oracle(w2o, mat, light, kinds, G[r0:r0 + nr], **kw)
+        assert_image_close(hi[r0:r0 + nr], oi, "image rows %d.." % r0)
+        flips += int((np.abs(hi[r0:r0 + nr] - oi).max(-1) > IMG_TOL).sum())
+        gw += ow; gm += om; gl += ol
+        if b in (2, 5):                                      # float32 floor on two bands (scaled up below): cheap enough
+            f = oracle(w2o, mat, light, kinds, G[r0:r0 + nr], dtype=torch.float32, **kw)
+            fw += f[1] - ow; fm += f[2] - om; fl += f[3] - ol
+    assert_grads_vs_oracle((hw, hm, hl), (gw, gm, gl), lambda: (gw + 4 * fw, gm + 4 * fm, gl + 4 * fl), flips, lambda: 0)
+
+
 def test_depth_shader(dev):
     from rrt import synthetic
     w2o, mat, light, kinds = synthetic.match_mirror(True)

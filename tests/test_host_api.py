@@ -270,3 +270,23 @@ def test_mgd_auto_optimizer_sgd_step():
     MGDAutoOptimizer(ae2).optimize([(X, 2 * X)], lam=0.5)(0.01)            # stereo pair, 1-D params at 0.1 x lr
     assert torch.allclose(ae2.W.detach(), torch.ones(2, 2) - 0.01 * (X.t() @ (2 * (out - 2 * X))))
     assert torch.allclose(ae2.b.detach(), -0.001 * 2 * (out - 2 * X)[0])
+
+
+def test_bench_refuses_to_run_on_fewer_gpus_than_asked():
+    """`bench.py --gpus N` never falls back to fewer GPUs (it used to print n_gpus = 1): on this
+    GPU-less host it must exit non-zero, before starting any rank, saying how many GPUs it sees; and a launcher's
+    WORLD_SIZE that disagrees with --gpus is an error too"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this host has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing to run on fewer" in (r.stderr + r.stdout)
+    assert not r.stdout.strip().startswith("{")
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "2", "0", "0"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
