@@ -614,11 +614,12 @@ RRT_HD bool adjoint_sphere_phong(const T* A, const T o[3], const T colI[3], T cm
   const T gta = g_t * ia;
   const T gD2 = -gta * ia * ih;                               // 2 g_D,  sqrt(Delta) = alpha h
   const T ca = gD2 * alpha;
-  const T cr = gD2 * Dp - (gta + gta) * t;
-  const T cop = gD2 * beta;
+  // g_r' = t g_p - gta o' + (gD2 D' - 2 gta t) r' + gD2 beta o_perp, with o' = o_perp + q r' (how o_perp was made):
+  const T cr = gD2 * Dp - gta * (t + t + q);
+  const T cop = gD2 * beta - gta;
   for (int c = 0; c < 3; ++c) {
     const T g_o = g_p[c] - gta * r[c] - ca * op[c];
-    const T g_r = t * g_p[c] - gta * o[c] + cr * r[c] + cop * op[c];
+    const T g_r = t * g_p[c] + cr * r[c] + cop * op[c];
     acc[ACC_RD + 3 * c + 0] += g_r * d[0];
     acc[ACC_RD + 3 * c + 1] += g_r * d[1];
     acc[ACC_RD + 3 * c + 2] += g_r * d[2];

@@ -1429,7 +1429,11 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
                               ? blockIdx.x + ((unsigned)a.n_bins - 1u - blockIdx.x) / gridDim.x * gridDim.x : 0u;
     const int n = local ? (blockIdx.x < (unsigned)a.n_bins ? a.S * ACC_STRIDE : 0) : a.B * a.S * ACC_STRIDE;
     float* dst = a.acc + (local ? (size_t)(last / (unsigned)a.bins_per_scene) * a.S * ACC_STRIDE : 0);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    // (every workgroup starts at a different shape row: they finish together and would otherwise all queue on row 0)
+    const int rot = n ? (int)((blockIdx.x * 5u * ACC_STRIDE) % (unsigned)n) : 0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += blockDim.x) {
+      int i = i0 + rot;
+      if (i >= n) i -= n;
       const float x = s_acc[i];
       if ((i & (ACC_STRIDE - 1)) < ACC_USED && x != 0.f)
         __hip_atomic_fetch_add(dst + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
