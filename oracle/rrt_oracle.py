@@ -445,10 +445,16 @@ def render(w2o, material, light, kinds=None, *, x_dims, y_dims,
 
 
 def hit_ids(w2o, kinds=None, *, x_dims, y_dims, antialias_samples=1,
-            cam_o2w=None, sample_dist=None, row0=0, rows=None, dtype=torch.float64):
+            cam_o2w=None, sample_dist=None, row0=0, rows=None, dtype=torch.float64, with_margin=False):
     """Index of the shape that wins the composite per (sample, pixel), -1 on
     miss.  Test helper: lets parity checks separate pixels whose winner differs
-    between float32 and float64 (silhouettes) from genuine errors."""
+    between float32 and float64 (silhouettes) from genuine errors.
+
+    ``with_margin=True`` also returns, per ray, min over the spheres of
+    |discriminant| / (p.v)^2 (shape.py:78-83's quantity, relative): how close the
+    ray is to grazing a sphere.  d colour / d parameter carries 1 / sqrt(discriminant)
+    (shape.py:109-126's sqrt), so rays with a tiny margin have unbounded weight in a
+    gradient and a float32 evaluation of them is ill-conditioned whoever does it."""
     w2o = torch.as_tensor(w2o).to(dtype)
     S = w2o.shape[0]
     if kinds is None:
@@ -465,7 +471,7 @@ def hit_ids(w2o, kinds=None, *, x_dims, y_dims, antialias_samples=1,
         rows = n_rows_full - row0
     band = (row0, row0 + rows)
     i_range, j_range = (None, band) if n_transposes % 2 == 1 else (band, None)
-    out = []
+    out, margins = [], []
     with torch.no_grad():
         for sample in range(A):
             rays = make_rays(x_dims, y_dims, sample_dist[:, :, sample, 0],
@@ -477,16 +483,24 @@ def hit_ids(w2o, kinds=None, *, x_dims, y_dims, antialias_samples=1,
                 origin, rays = transform_apply(cam, origin, rays)
             ids = None
             min_dists = None
+            margin = None
             for k in range(S):
                 o_k, r_k = transform_apply(w2o[k], origin, rays)
                 dists = shape_distance(kinds[k], r_k, o_k)
                 if ids is None:
                     ids = torch.full(dists.shape, -1, dtype=torch.int64)
                     min_dists = torch.full(dists.shape, INF, dtype=dtype)
+                    margin = torch.full(dists.shape, INF, dtype=dtype)
                 sel = dists < min_dists
                 ids = torch.where(sel, torch.full_like(ids, k), ids)
                 min_dists = torch.where(sel, dists, min_dists)
+                if with_margin and kinds[k] == SPHERE:
+                    pdotv = torch.tensordot(r_k, o_k, dims=1)
+                    margin = torch.minimum(margin, sphere_hit(r_k, o_k).abs() / (pdotv * pdotv).clamp_min(1e-300))
             out.append(ids)
+            margins.append(margin)
+    if with_margin:
+        return torch.stack(out), torch.stack(margins)
     return torch.stack(out)
 
 

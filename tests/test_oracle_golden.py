@@ -131,3 +131,31 @@ def test_hash_jitter_is_uniform_and_reproducible():
     sd = O.sample_dist_from_uniform(U)                    # scene.py:31-32 strata
     for s in range(4):
         assert sd[:, :, s].min() >= s / 4 and sd[:, :, s].max() < (s + 1) / 4
+
+
+def test_hit_ids_and_grazing_margin():
+    """the parity tests' helpers: winner index per ray in the image's orientation, and the relative
+    discriminant margin that marks the rays whose gradient weight 1 / sqrt(discriminant) is unbounded"""
+    w2o = torch.stack([O.translate((-.5, -.5, 4.))[1], O.translate((.5, .5, 4.))[1]])
+    mat = torch.tensor([[.2, .9, .4, .3, .7, .5, 50.], [.87, .1, .507, .3, .9, .4, 50.]], dtype=torch.float64)
+    light = torch.tensor([-1., -1., 2., 1., .87, .961], dtype=torch.float64)
+    n, A = 96, 2
+    sd = O.sample_dist_from_uniform(O.hash_u01(5, n, n, A))
+    kw = dict(x_dims=n, y_dims=n, antialias_samples=A, sample_dist=sd, row0=16, rows=48)
+    ids, margin = O.hit_ids(w2o, with_margin=True, **kw)
+    img = O.render(w2o, mat, light, **kw)
+    assert ids.shape == margin.shape == (A, 48, n) and img.shape == (48, n, 3)
+    assert torch.equal((ids >= 0).any(0), img.sum(-1) > 0)
+    assert set(ids.unique().tolist()) == {-1, 0, 1}
+    near = margin.amin(0) < 1e-3
+    assert 0 < int(near.sum()) < 0.05 * near.numel()
+    # one sphere: every near-grazing ray is at (or next to) a pixel where the hit mask changes
+    ids1, m1 = O.hit_ids(w2o[:1], with_margin=True, **kw)
+    hit = ids1[0] >= 0
+    edge = torch.zeros_like(hit)
+    edge[1:-1, 1:-1] = (hit[1:-1, 1:-1] != hit[:-2, 1:-1]) | (hit[1:-1, 1:-1] != hit[2:, 1:-1]) | \
+        (hit[1:-1, 1:-1] != hit[1:-1, :-2]) | (hit[1:-1, 1:-1] != hit[1:-1, 2:])
+    grown = edge.clone()
+    grown[1:, :] |= edge[:-1, :]; grown[:-1, :] |= edge[1:, :]; grown[:, 1:] |= edge[:, :-1]; grown[:, :-1] |= edge[:, 1:]
+    near0 = m1[0] < 1e-3
+    assert int(near0[1:-1, 1:-1].sum()) > 0 and bool((near0[1:-1, 1:-1] <= grown[1:-1, 1:-1]).all())
