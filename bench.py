@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup-ms", type=float, default=50.0,
+                    help="untimed device spin-up before the W warmup steps (the clocks settle over the first tens of "
+                         "milliseconds of work; reported in config.spinup_ms)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--spheres", type=int, default=32)
     ap.add_argument("--aa", type=int, default=1)
@@ -234,6 +237,24 @@ def parity_sample(dev, size, spheres, aa, rows=48):
             "max_rel_dgrad": {"w2o": rw, "material": rm, "light": rl}}
 
 
+def time_kernels(job, n):
+    """median duration (s) of k_fwd and of k_bwd over n back-to-back launches of each"""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+    job.fwd()
+    torch.cuda.synchronize()
+    for i in range(n):
+        ev[i][0].record()
+        job.fwd(reuse=True)              # k_fwd alone (packed scene + tile lists reused)
+        ev[i][1].record()
+        job.bwd(kernel_only=True)        # k_bwd alone (RRT_FLAG_SKIP_FINALIZE)
+        ev[i][2].record()
+    job.fwd()                            # re-pack: rewinds the accumulators the kernel-only calls left dirty
+    torch.cuda.synchronize()
+    t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+    t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    return t_f, t_b
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -284,6 +305,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed spin-up: a GPU that has been idle runs its first ~30 ms of work 4-5 % slower (clocks), and the timed
+    # region may be as short as 2 ms (--steps 20).  Then the W warmup steps, then exactly K timed steps.
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+        for _ in range(10):               # no collective in here: the ranks' loop counts differ
+            job.fwd()
+            job.bwd()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -300,24 +329,11 @@ def main():
     rays = job.B * full_rows * args.size * args.aa
     value = rays / (elapsed / args.steps) / 1e6
 
-    # per-kernel durations, HIP events on the launch stream (torch's current stream)
     roofline = None
     kernels = None
     if not args.no_kernel_timing:
-        n = max(20, min(args.steps, 100))
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
-        job.fwd()
-        torch.cuda.synchronize()
-        for i in range(n):
-            ev[i][0].record()
-            job.fwd(reuse=True)              # k_fwd alone (packed scene + tile lists reused)
-            ev[i][1].record()
-            job.bwd(kernel_only=True)        # k_bwd alone (RRT_FLAG_SKIP_FINALIZE)
-            ev[i][2].record()
-        job.fwd()                            # re-pack: rewinds the accumulators the kernel-only calls left dirty
-        torch.cuda.synchronize()
-        t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
-        t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+        # per-kernel durations: HIP events on the launch stream (torch's current stream), 100 launches of each kernel
+        t_f, t_b = time_kernels(job, 100)
         px = job.B * rows * args.size
         kernels = {"k_fwd_us": t_f * 1e6, "k_bwd_us": t_b * 1e6,
                    "k_fwd_GBs": px * BYTES_PER_PIXEL_FWD / t_f / 1e9,
@@ -383,7 +399,7 @@ def main():
                                           "antialias_samples=4, hash jitter",
                                     "c5": "config 5: 256 orbit scenes (2 spheres, stereo cameras, no specular), 64x64, "
                                           "antialias_samples=4, one batched launch"}[args.workload],
-                       "cull": not args.no_cull, "parallelism": "rowband%d" % world},
+                       "cull": not args.no_cull, "parallelism": "rowband%d" % world, "spinup_ms": args.spinup_ms},
             "roofline": roofline, "roofline_other_kernel": roofline_other, "kernels": kernels, "cpu_baseline": cpu,
             "parity": parity,
         }
