@@ -114,3 +114,10 @@ print("workgroup finish (us): min %.1f p10 %.1f median %.1f p90 %.1f max %.1f; t
       "sum of tile times per workgroup (us): min %.0f median %.0f max %.0f" % (
           last.min(), np.percentile(last, 10), np.median(last), np.percentile(last, 90), last.max(), cntw.min(), cntw.max(),
           busy.min(), np.median(busy), busy.max()))
+print("tiles per workgroup: percentiles 0/10/50/90/100 = %s; workgroups seen %d" % (
+    np.percentile(cntw, [0, 10, 50, 90, 100]).tolist(), (cntw > 0).sum()))
+order = np.argsort(last)
+print("the 8 last workgroups to finish: id %s tiles %s busy(us) %s" % (order[-8:].tolist(), cntw[order[-8:]].tolist(),
+                                                                       np.round(busy[order[-8:]]).tolist()))
+print("the 8 first: id %s tiles %s busy(us) %s" % (order[:8].tolist(), cntw[order[:8]].tolist(), np.round(busy[order[:8]]).tolist()))
+print("correlation(finish time, tiles) = %.2f, (finish time, busy) = %.2f" % (np.corrcoef(last, cntw)[0, 1], np.corrcoef(last, busy)[0, 1]))
