@@ -359,6 +359,8 @@ def main():
                 k = prof[name]
                 r["traffic"] = k["hbm_bytes"]
                 r["traffic_source"] = "from_profile: profiles/r02_counters.json (%s)" % prof["source"]
+                # rocprofv3's own begin-to-end duration of the dispatch; `us` (HIP events) also holds the launch gap
+                r["us_kernel_trace_from_profile"] = k["avg_us_kernel_trace"]
                 hbm_real = k["hbm_bytes"] / t / 1e9
                 peak = prof["valu_peak_inst_per_cycle_per_simd"] * prof["simds"] * prof["clock_ghz"]      # Ginst/s
                 r["valu_Ginst_s"] = k["valu_insts"] / t / 1e9
