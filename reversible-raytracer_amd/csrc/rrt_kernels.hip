@@ -146,6 +146,17 @@ struct KArgs {
   float* acc;                     // bwd: [B][S][ACC_STRIDE]
 };
 
+// The render kernels carry ~170 scalar values over their tile loops and spill them into vector lanes; every use is then a
+// v_readlane, a VALU instruction of the slow class.  What a tile needs of the kernel arguments only at its start or end is
+// therefore read from the kernarg segment where it is used (a scalar load, off the VALU): the `asm` keeps the compiler from
+// hoisting the loads to the kernel's top.  Every kernel here takes the KArgs struct first (offset 0 of the segment).
+typedef const __attribute__((address_space(4))) KArgs* ckargs;
+__device__ __forceinline__ ckargs kargs_here() {
+  ckargs p = (ckargs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 struct Tile {
   int b, a0, b0, nrows, ncols;    // scene, first row (window-relative), first column, extent
 };
@@ -164,11 +175,12 @@ __device__ __forceinline__ Tile decode_entry(const KArgs& a, unsigned long long 
   t.b = (int)((e >> 36) & 0xffffu);
   k0 = (int)((e >> 52) & 0x3ffu);
   multi = ((e >> 62) & 1u) != 0;
-  t.a0 = ty * a.P;
+  ckargs ka = kargs_here();
+  t.a0 = ty * ka->P;
   t.b0 = tx * TILE_W;
-  t.nrows = min(a.P, a.v.rows - t.a0);
-  t.ncols = min(TILE_W, a.v.ncols - t.b0);
-  tile = ((long long)t.b * a.tiles_y + ty) * a.tiles_x + tx;
+  t.nrows = min(ka->P, ka->v.rows - t.a0);
+  t.ncols = min(TILE_W, ka->v.ncols - t.b0);
+  tile = ((long long)t.b * ka->tiles_y + ty) * ka->tiles_x + tx;
   return t;
 }
 
@@ -200,7 +212,8 @@ __device__ __forceinline__ unsigned long long lane_bcast64(unsigned long long v,
 // Index of shape k of scene b in the LDS copy of the scene(s): the whole batch (lds_scene = 1) or only the
 // scene of the list segment the workgroup is working on (lds_scene = 2).
 __device__ __forceinline__ size_t lds_rec(const KArgs& a, int b, int k) {
-  return (size_t)(a.lds_scene == 2 ? 0 : b) * a.S + k;
+  ckargs ka = kargs_here();
+  return (size_t)(ka->lds_scene == 2 ? 0 : b) * ka->S + k;
 }
 
 // One shape's packed record as wave-uniform scalars (SGPRs).
@@ -241,8 +254,9 @@ __device__ __forceinline__ void load_shape(const KArgs& a, const float* lds, int
 // The same in two steps, for callers that decide on kind / flags first and then want only a part:
 // `word` is the record as one VGPR (lane l holds word l); the pieces are v_readlane broadcasts of it.
 __device__ __forceinline__ float shape_word(const KArgs& a, const float* lds, int b, int k, int lane) {
-  return a.lds_scene ? lds[lds_rec(a, b, k) * PS_STRIDE + (lane & 31)]
-                     : a.ps[((size_t)b * a.S + k) * PS_STRIDE + (lane & 31)];
+  ckargs ka = kargs_here();
+  return ka->lds_scene ? lds[lds_rec(a, b, k) * PS_STRIDE + (lane & 31)]
+                       : ka->ps[((size_t)b * ka->S + k) * PS_STRIDE + (lane & 31)];
 }
 __device__ __forceinline__ void shape_head(float word, ShapeP& q) {
   q.kind = ps_load_int(lane_bcast(word, PS_KIND));
@@ -265,8 +279,9 @@ __device__ __forceinline__ void shape_transform(float word, ShapeP& q) {
 // broadcast ds_read_b128, A' and o' are the first 12 words of the record).
 __device__ __forceinline__ void load_shape_vgpr(const KArgs& a, const float* lds, int b, int k, float Av[9], float ov[3]) {
   // (from global memory when the scene is not staged: still every lane the same address, one request)
-  const float4* r = reinterpret_cast<const float4*>(a.lds_scene ? lds + lds_rec(a, b, k) * PS_STRIDE
-                                                                : a.ps + ((size_t)b * a.S + k) * PS_STRIDE);
+  ckargs ka = kargs_here();
+  const float4* r = reinterpret_cast<const float4*>(ka->lds_scene ? lds + lds_rec(a, b, k) * PS_STRIDE
+                                                                  : ka->ps + ((size_t)b * ka->S + k) * PS_STRIDE);
   const float4 x0 = r[0], x1 = r[1], x2 = r[2];
   Av[0] = x0.x; Av[1] = x0.y; Av[2] = x0.z; Av[3] = x0.w; Av[4] = x1.x; Av[5] = x1.y; Av[6] = x1.z; Av[7] = x1.w;
   Av[8] = x2.x; ov[0] = x2.y; ov[1] = x2.z; ov[2] = x2.w;
@@ -281,7 +296,7 @@ struct SceneP {
   float L[3], look[3], Llook;
 };
 __device__ __forceinline__ void load_scene(const KArgs& a, int b, SceneP& sc) {
-  cfptr hdr = as_const(a.hdr) + (size_t)b * HDR_STRIDE;
+  cfptr hdr = as_const(kargs_here()->hdr) + (size_t)b * HDR_STRIDE;
 #pragma unroll
   for (int n = 0; n < 3; ++n) { sc.L[n] = hdr[HDR_LHAT + n]; sc.look[n] = hdr[HDR_LOOK + n]; }
   sc.Llook = hdr[HDR_LLOOK];
@@ -877,7 +892,7 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
         load_scene(a, t.b, sc);
         b_cur = t.b;
       }
-      cuptr mk = as_const(a.mask) + tile * a.nwords;
+      cuptr mk = as_const(kargs_here()->mask) + tile * kargs_here()->nwords;
       const LaneRay lr = lane_ray<TR>(a, t, lane);
       float c[P][3];
 #pragma unroll
@@ -1059,8 +1074,9 @@ __device__ __forceinline__ void prefetch_grad_rows(const KArgs& a, const Tile& t
   (void)lane_unused;
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   // one address computation per tile, one add per row
-  const size_t row_bytes = (size_t)a.v.ncols * 12;
-  const char* row = reinterpret_cast<const char*>(a.grad) + ((size_t)t.b * a.v.rows + t.a0) * row_bytes + (size_t)t.b0 * 12;
+  ckargs ka = kargs_here();
+  const size_t row_bytes = (size_t)ka->v.ncols * 12;
+  const char* row = reinterpret_cast<const char*>(ka->grad) + ((size_t)t.b * ka->v.rows + t.a0) * row_bytes + (size_t)t.b0 * 12;
   if (t.ncols == TILE_W) {
     // the usual case, a full-width tile: 48 lanes x 16 bytes per row
     if (lane < TILE_W * 3 / 4) {
@@ -1140,7 +1156,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
     prefetch_grad_rows<P>(a, tn, lane, s_up_wave + (w.buf ^ 1) * (P * UP_ROW));
   }
   const LaneRay lr = lane_ray<TR>(a, t, lane);
-  cuptr mk = as_const(a.mask) + tile * a.nwords;
+  cuptr mk = as_const(kargs_here()->mask) + tile * kargs_here()->nwords;
   RRT_STAMP(2);
 
 #pragma unroll 1
