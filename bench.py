@@ -56,6 +56,8 @@ def parse():
                          "c3: match_mirror scene (2 spheres + square) 1024^2, A=4; c5: 256 orbit scenes of 64^2, A=4")
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline band (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the all-reduce / barrier path even at world size 1 (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the fixed --size^2 image cut into N row bands (BASELINE configs[3]); "
                          "weak = --size rows PER GPU (the image grows to N*size x size rays)")
@@ -270,10 +272,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path is HIP only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1
+    use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from rrt.dist import band
     if args.workload == "c2":
