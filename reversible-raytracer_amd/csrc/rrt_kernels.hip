@@ -295,8 +295,11 @@ __device__ __forceinline__ void load_shape_vgpr(const KArgs& a, const float* lds
 struct SceneP {
   float L[3], look[3], Llook;
 };
-__device__ __forceinline__ void load_scene(const KArgs& a, int b, SceneP& sc) {
-  cfptr hdr = as_const(kargs_here()->hdr) + (size_t)b * HDR_STRIDE;
+// (`ka`: where the kernel arguments are read from.  The default is evaluated in the caller, i.e. inside a kernel;
+// bwd_generic_shape -- a real function, in which the kernarg-segment builtin yields NULL -- passes the pointer its kernel
+// gave it)
+__device__ __forceinline__ void load_scene(const KArgs& a, int b, SceneP& sc, ckargs ka = kargs_here()) {
+  cfptr hdr = as_const(ka->hdr) + (size_t)b * HDR_STRIDE;
 #pragma unroll
   for (int n = 0; n < 3; ++n) { sc.L[n] = hdr[HDR_LHAT + n]; sc.look[n] = hdr[HDR_LOOK + n]; }
   sc.Llook = hdr[HDR_LLOOK];
@@ -1115,6 +1118,83 @@ struct BwdWave {
   float held_val;
 };
 
+// The GENERIC adjoint of one shape over one tile -- squares, the depth shader, dark or negative colours, exponents
+// <= 1 -- as a function of its own (centre-jitter kernels only, see its call).  Inlined as a branch beside the hot path
+// it shares the tile body's register allocation: the hot path (FAST_* spheres, all of the bench scene) ran with 41
+// spilled vector registers and scratch accesses; without that branch it needs 122 registers and none (k_bwd 38.0 ->
+// 36.1 us), with the branch as a call 123 and none, but calls pin scalar values to the callee-saved registers: 36.8 us.
+// The 22 sums come back by value (a stack slot), the kernel arguments are re-read from the kernarg segment; both are
+// noise beside the ~260 VALU instructions of a generic row.
+struct GenericSums {
+  float v[ACC_USED];
+  int anyhit;
+};
+template <int P, int SHADER, int SPEC, int JC, int TR, bool MULTI>
+__device__ __attribute__((noinline)) GenericSums bwd_generic_shape(int tb, int ta0, int tnrows, int k, int s_lo, int s_hi,
+                                                                  float lr_cl, float lr_q, int lr_col, int col_ok_i,
+                                                                  float qword, unsigned up_at, unsigned best_at,
+                                                                  unsigned long long kernarg) {
+  // (arguments arrive in vector registers: the wave-uniform ones are made scalar again.  The builtin returns int:
+  // mind the sign extension when two halves are glued)
+  auto uni = [](unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane(x); };
+  tb = (int)uni(tb); ta0 = (int)uni(ta0); tnrows = (int)uni(tnrows); k = (int)uni(k); s_lo = (int)uni(s_lo); s_hi = (int)uni(s_hi);
+  // the wave's gradient rows and winner table, as LDS offsets (generic pointers to LDS passed into a real function send
+  // this compiler into "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+  typedef __attribute__((address_space(3))) const float* lcf;
+  typedef __attribute__((address_space(3))) const int* lci;
+  const lcf up_rows = (lcf)(size_t)uni(up_at);
+  const lci best = (lci)(size_t)uni(best_at);
+  // the kernel's kernarg pointer comes as an argument: __builtin_amdgcn_kernarg_segment_ptr() is NULL in a real
+  // function (tools/ubench/noinline_probe.hip)
+  const ckargs ka = (ckargs)(((unsigned long long)uni((unsigned)(kernarg >> 32)) << 32) | uni((unsigned)kernarg));
+  KArgs a;
+  {
+    static_assert(sizeof(KArgs) % 4 == 0, "copied as dwords");
+    cu32ptr src = (cu32ptr)ka;
+    unsigned words[sizeof(KArgs) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(KArgs) / 4; ++i) words[i] = src[i];
+    __builtin_memcpy(&a, words, sizeof(KArgs));
+  }
+  const ViewK& v = a.v;
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const bool col_ok = col_ok_i != 0;
+  LaneRay lr;
+  lr.cl = lr_cl; lr.q = lr_q; lr.col = lr_col;
+  SceneP sc;
+  load_scene(a, tb, sc, ka);
+  ShapeP q;
+  shape_head(qword, q);
+  shape_material(qword, q);
+  shape_transform(qword, q);
+  GenericSums out;
+  float* acc = out.v;
+#pragma unroll
+  for (int n = 0; n < ACC_USED; ++n) acc[n] = 0.f;
+  bool anyhit = false;
+  __builtin_amdgcn_s_setprio(0);                     // (as in the hot path)
+#pragma unroll 1
+  for (int s = s_lo; s < s_hi; ++s) {
+    float jcx, jcy;
+    centre_jitter(v, s, jcx, jcy);
+#pragma unroll 1
+    for (int p = 0; p < tnrows; ++p) {
+      const bool on = MULTI ? (best[p * 64 + lane] == k) : col_ok;
+      if (on) {
+        float d[3];
+        row_ray<JC, TR>(a, lr, ta0 + p, s, jcx, jcy, d);
+        const lcf ur = up_rows + p * UP_ROW + 3 * lane;
+        const float up[3] = {ur[0], ur[1], ur[2]};
+        anyhit |= adjoint_ray<float>(q.kind, q.A, q.o, q.colI, q.ks, q.kd, q.ka, q.sh, q.powf, SHADER, SPEC,
+                                     v.inv_max_depth, sc.L, sc.look, d, up, acc);
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(2);
+  out.anyhit = anyhit ? 1 : 0;
+  return out;
+}
+
 // One tile of the backward pass.  MULTI = the tile has several candidate shapes: per sample, every
 // ray's winner is settled first and the adjoint then runs per winning shape.  !MULTI (two thirds of
 // the bench scene's tiles, and the cheap ones to get right): one candidate, no winner search, the
@@ -1255,7 +1335,11 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
         }
         __builtin_amdgcn_s_setprio(2);
         adjoint_sphere_phong_finish<float>(gs_sum, lookv, acc);
-      } else {
+      } else if (SH || !JC) {
+        // The generic adjoint inline.  The centre-jitter kernels call it as a function instead (bwd_generic_shape, below):
+        // measured per kernel -- the call's register convention costs the hash / explicit-jitter kernels 4-12 us (C3,
+        // C5), and the shadows extension walks the LDS scene through generic pointers, which this compiler cannot handle
+        // inside a real function.
         shape_transform(qword, q);
         __builtin_amdgcn_s_setprio(0);               // (as above)
 #pragma unroll 1
@@ -1288,6 +1372,15 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
           }
         }
         __builtin_amdgcn_s_setprio(2);
+      } else {
+        typedef __attribute__((address_space(3))) const float* lcf;
+        typedef __attribute__((address_space(3))) const int* lci;
+        const GenericSums g = bwd_generic_shape<P, SHADER, SPEC, JC, TR, MULTI>(
+            t.b, t.a0, t.nrows, k, s_lo, s_hi, lr.cl, lr.q, lr.col, col_ok ? 1 : 0, qword,
+            (unsigned)(size_t)(lcf)up_rows, (unsigned)(size_t)(lci)&s_best_wave[0][0], (unsigned long long)kargs_here());
+#pragma unroll
+        for (int n = 0; n < ACC_USED; ++n) acc[n] = g.v[n];
+        anyhit = g.anyhit != 0;
       }
       RRT_STAMP(5);
       if (!__ballot(anyhit)) continue;
