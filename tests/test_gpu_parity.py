@@ -795,20 +795,15 @@ def _random_scene(rs):
     return w2o.astype(np.float32), mat.astype(np.float32), light.astype(np.float32), kinds
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_random_scenes_vs_oracle(dev, seed):
-    """seeded sweep over what the boundary accepts: general affine shapes (Spheres and Squares),
-    ragged image sizes on either side of the tile-row heuristic, 1..3 samples with hash jitter,
-    Phong with / without specular and the depth shader, root and orbit camera.  Image against the
-    float64 oracle; gradients against it up to the float32 noise floor the oracle itself shows
-    when run in float32 at the same point (grazing rays)."""
+def _random_scene_case(dev, seed, centre):
     rs = np.random.RandomState(1000 + seed)
     w2o, mat, light, kinds = _random_scene(rs)
     x = int(rs.choice([33, 64, 100, 130, 257]))
     y = x if rs.rand() < 0.6 else int(rs.choice([48, 96, 192]))
     A = int(rs.randint(1, 4))
     shader = "depth" if seed % 4 == 3 else "phong"
-    kw = dict(x_dims=x, y_dims=y, antialias_samples=A, jitter=int(rs.randint(1, 1 << 20)), shader=shader,
+    jit = int(rs.randint(1, 1 << 20))
+    kw = dict(x_dims=x, y_dims=y, antialias_samples=A, jitter="center" if centre else jit, shader=shader,
               specular=bool(rs.rand() < 0.7), max_depth=12.0)
     if x != y or seed % 3 == 0:                               # the root camera of the reference only works for squares
         kw["cam"] = synthetic_orbit_cam(float(rs.uniform(-0.5, 0.5)))
@@ -821,6 +816,24 @@ def test_random_scenes_vs_oracle(dev, seed):
     assert_grads_vs_oracle((hw, hm, hl), (ow, om, ol),
                            lambda: oracle(w2o, mat, light, kinds, G, dtype=torch.float32, **kw)[1:],
                            image_flips, lambda: oracle(w2o, mat, light, kinds, G, want_flips=True, **kw))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_vs_oracle(dev, seed):
+    """seeded sweep over what the boundary accepts: general affine shapes (Spheres and Squares),
+    ragged image sizes on either side of the tile-row heuristic, 1..3 samples with hash jitter,
+    Phong with / without specular and the depth shader, root and orbit camera.  Image against the
+    float64 oracle; gradients against it up to the float32 noise floor the oracle itself shows
+    when run in float32 at the same point (grazing rays)."""
+    _random_scene_case(dev, seed, centre=False)
+
+
+@pytest.mark.parametrize("seed", range(12, 20))
+def test_random_scenes_centre_jitter(dev, seed):
+    """the same sweep at the stratum centres: the centre-jitter kernels are instantiations of their own (JC = 1), and
+    their backward runs squares, the depth shader and non-FAST materials through a called function (bwd_generic_shape)
+    where the others have the code inline"""
+    _random_scene_case(dev, seed, centre=True)
 
 
 def synthetic_orbit_cam(y):
