@@ -14,7 +14,11 @@ floor of the same formulas measured on the CPU harness (test_device_math.py):
     max|d| <= 4 x (float32 oracle's error), and that only up to GRAD_RTOL * max|g|
     (5e-3; 2e-2 for the thin white-noise band) unless a hit/miss flip is actually
     present (a pixel of the GPU image off by more than IMG_TOL, or a ray whose
-    winner differs between the float32 and the float64 oracle, ``oracle.hit_ids``);
+    winner differs between the float32 and the float64 oracle, ``oracle.hit_ids``).
+    With such an undecidable ray present even that bound can fail -- the ray's
+    weight 1 / sqrt(discriminant) is unbounded and one of them can outweigh the
+    rest of the image (seen: 8.7 x max|g| at 33 x 33 pixels) -- and then the
+    masked comparison below is the test;
   * per entry: every gradient entry, small ones included, within
     max(ENTRY_RTOL * |entry|, 4 x the float32 oracle's error on that entry,
     ENTRY_FLOOR * max|g|) -- so an entry above ENTRY_FLOOR/ENTRY_RTOL of the
@@ -169,6 +173,13 @@ def assert_grads_vs_oracle(got, ref, f32, image_flips, count_flips, loose=None):
             tol, fallback = max(tol, fl if flips() > 0 else min(fl, cap)), True
             used_fallback = True
         _note(what, float(err.max() / scale), cache.get("flips", image_flips), fallback)
+        if fallback and flips() > 0 and err.max() > tol:
+            # A ray whose hit / miss is undecidable in float32 is present, and its weight 1 / sqrt(discriminant) has no
+            # bound: one such ray can outweigh the rest of the image (seen: 8.7 x max|g|), in the GPU's float32, in the
+            # float32 oracle's, or in both, differently.  No bound on the full sum is meaningful then -- the caller's
+            # comparison with the grazing pixels masked (check_scene) is the test, and it has no fallback.
+            _note(what + " [undecidable ray: masked comparison decides]", float(err.max() / scale), flips(), True)
+            continue
         assert err.max() <= tol, "%s: max|d|=%g vs scale %g (rel %.2e), flips %d" % (what, err.max(), scale, err.max() / scale,
                                                                                     flips())
         # per entry (small entries too)
@@ -208,16 +219,20 @@ def check_scene(dev, w2o, mat, light, kinds, seed=0, grad_rtol=None, **kw):
                                        lambda: oracle(w2o, mat, light, kinds, G, dtype=torch.float32, **okw)[1:],
                                        image_flips, lambda: oracle(w2o, mat, light, kinds, G, want_flips=True, **okw),
                                        loose=grad_rtol)
-    if fell_back and okw.get("shader", "phong") == "phong":
-        # the tight bound was missed: show that the near-grazing rays (module docstring) are the whole reason --
-        # with their pixels' upstream gradient zeroed, GPU and oracle must agree to 1e-3 with no fallback
-        well = oracle(w2o, mat, light, kinds, None, want_margin=True, **okw) >= GRAZING_MARGIN
-        assert (~well).sum() < 0.25 * well.size, (~well).sum()
-        Gw = G * well[:, :, None]
-        _, *h_well = hip_render(dev, w2o, mat, light, kinds, grad=Gw, **kw)
-        _, *o_well = oracle(w2o, mat, light, kinds, Gw, **okw)
-        assert_grads_tight(h_well, o_well, "grazing pixels masked: %d of %d" % ((~well).sum(), well.size))
+    if fell_back:
+        assert_grads_without_grazing_pixels(dev, w2o, mat, light, kinds, G, kw, okw)
     return hi
+
+
+def assert_grads_without_grazing_pixels(dev, w2o, mat, light, kinds, G, kw, okw):
+    """the tight bound was missed on the full upstream gradient: show that the near-grazing rays (module docstring)
+    are the whole reason -- with their pixels' upstream gradient zeroed, GPU and oracle must agree to 1e-3, no fallback"""
+    well = oracle(w2o, mat, light, kinds, None, want_margin=True, **okw) >= GRAZING_MARGIN
+    assert 0 < (~well).sum() < 0.25 * well.size, (~well).sum()
+    Gw = G * well[:, :, None]
+    _, *h_well = hip_render(dev, w2o, mat, light, kinds, grad=Gw, **kw)
+    _, *o_well = oracle(w2o, mat, light, kinds, Gw, **okw)
+    assert_grads_tight(h_well, o_well, "grazing pixels masked: %d of %d" % ((~well).sum(), well.size))
 
 
 # ---------------------------------------------------------------- configs --
@@ -813,9 +828,10 @@ def _random_scene_case(dev, seed, centre):
     oi, ow, om, ol = oracle(w2o, mat, light, kinds, G, **kw)
     assert_image_close(hi, oi, "image")
     image_flips = int((np.abs(hi - oi).max(-1) > IMG_TOL).sum())
-    assert_grads_vs_oracle((hw, hm, hl), (ow, om, ol),
-                           lambda: oracle(w2o, mat, light, kinds, G, dtype=torch.float32, **kw)[1:],
-                           image_flips, lambda: oracle(w2o, mat, light, kinds, G, want_flips=True, **kw))
+    if assert_grads_vs_oracle((hw, hm, hl), (ow, om, ol),
+                              lambda: oracle(w2o, mat, light, kinds, G, dtype=torch.float32, **kw)[1:],
+                              image_flips, lambda: oracle(w2o, mat, light, kinds, G, want_flips=True, **kw)):
+        assert_grads_without_grazing_pixels(dev, w2o, mat, light, kinds, G, kw, dict(kw))
 
 
 @pytest.mark.parametrize("seed", range(12))
