@@ -36,7 +36,18 @@ CASES = {
     "random8_band": dict(scene=lambda: syn.random_spheres(8, seed=3), n=64, A=1, row0=17, rows=30),
     "orbit": dict(scene=syn.orbit_scene, n=48, A=4, jitter=11, cam=syn.orbit_camera(2.5), specular=False),
     "one_sphere": dict(scene=syn.one_sphere, n=32, A=1),
+    # pure colours (a colour channel exactly 0, planet_orbit.py:26-33) lit from behind: phi < 0 on most of what the camera
+    # sees -- the FAST_ZEROCH corner of the lean adjoint (the zero channel's d/dcolour = phi survives the clip at 0)
+    "backlit_pure": dict(scene=lambda: _backlit_pure_scene(), n=40, A=2, jitter=4),
+    "backlit_pure_nospec": dict(scene=lambda: _backlit_pure_scene(), n=40, A=2, jitter=4, specular=False),
 }
+
+
+def _backlit_pure_scene():
+    w2o = np.stack([syn._w2o_translate_scale((-0.6, -0.2, 4.0), 1.0), syn._w2o_translate_scale((0.7, 0.4, 5.0), 1.2)])
+    mat = np.array([[0.0, 0.9, 0.0, 0.3, 0.9, 0.1, 7.0], [0.8, 0.0, 0.6, 0.2, 0.7, 0.15, 20.0]])
+    light = np.array([0.3, 0.2, -1.0, 1.0, 0.9, 0.8])
+    return w2o.astype(np.float32), mat.astype(np.float32), light.astype(np.float32), np.zeros(2, dtype=np.uint8)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -163,7 +174,7 @@ def test_degenerate_transform_is_never_culled():
     assert v == 0 and mean == 1.0
 
 
-@pytest.mark.parametrize("name", ["match_mirror_aa_hash", "random8", "orbit", "one_sphere"])
+@pytest.mark.parametrize("name", ["match_mirror_aa_hash", "random8", "orbit", "one_sphere", "backlit_pure", "backlit_pure_nospec"])
 def test_fast_paths_equal_generic_paths(name):
     """the lean code paths the kernels take for FAST_* shapes (shade_phong_fast, adjoint_sphere_phong:
     spheres with positive colour x intensity, shininess > 1) against the generic ones (shade_phong,

@@ -609,7 +609,15 @@ def test_c5_batch_256_orbit_scenes(dev):
         gl += ol
         if b in (0, 1, 37, 95, 128, 255):
             assert_image_close(img[b].detach().cpu().double().numpy(), oi, "image[%d]" % b)
-            assert_grad_close(tw.grad[b].cpu().double().numpy(), ow, "g_w2o[%d]" % b, rtol=GRAD_TIGHT)
+            hwb = tw.grad[b].cpu().double().numpy()
+            rel = np.abs(hwb - ow).max() / np.abs(ow).max()
+            _note("g_w2o[%d]" % b, float(rel), 0, bool(rel > GRAD_TIGHT))
+            if rel > GRAD_TIGHT:
+                # (a grazing ray in this scene: the rule of the module docstring, on the scene rendered alone -- the
+                # batched launch equals B single launches, test_batch_axis)
+                assert rel <= GRAD_RTOL, "g_w2o[%d]: rel %.2e" % (b, rel)
+                kw1 = dict(x_dims=n, y_dims=n, antialias_samples=4, specular=False, jitter=4, cam=cams[b])
+                assert_grads_without_grazing_pixels(dev, w[b], mat, light, kinds, G[b].astype(np.float64), kw1, dict(kw1))
     # shared material / light gradients are summed over the batch
     assert_grad_close(tm.grad.cpu().double().numpy(), gm, "g_material summed over the batch", rtol=GRAD_TIGHT)
     # (the light's gradient is a sum over 256 scenes with opposite signs -- the two cameras look from either side:
