@@ -46,6 +46,7 @@
 // rows, persistent grid sizes, LDS staging on/off, queue batch size, saved queues
 // on/off); defaults are what was measured best.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -140,6 +141,7 @@ struct KArgs {
   int use_saved;                  // share back (1) instead of redoing scans, searches and the entry gather
   int chunk;                      // list segments per queue batch: at most one per thread, and few enough that a
                                   // workgroup's share of their tiles fits its queues (Q_CAP)
+  int zw_even, zw_odd;            // k_fwd: shares of the zero-filled tiles, workgroups with even : odd blockIdx (XcdDeal)
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
@@ -594,6 +596,13 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
   }
 }
 
+// First row of tile t in an image / gradient buffer [B][rows][ncols][3], as a wave-uniform byte pointer.
+__device__ __forceinline__ char* tile_row_ptr(const float* buf, const Tile& t) {
+  ckargs ka = kargs_here();
+  const size_t row_bytes = (size_t)ka->v.ncols * 12;
+  return reinterpret_cast<char*>(const_cast<float*>(buf)) + ((size_t)t.b * ka->v.rows + t.a0) * row_bytes + (size_t)t.b0 * 12;
+}
+
 // ---- per-workgroup work queue ------------------------------------------------
 // Workgroup wg owns entries wg, wg + n_wgs, ... of a tile list (a fair, spatially
 // interleaved share).  They are copied into LDS once and handed to the
@@ -601,7 +610,10 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
 // atomics): a tile costs 1x..3x depending on its candidates and coverage, and a
 // static deal per WAVE left most SIMDs idle behind the unluckiest wave
 // (profiles/: 2.6 of 4 resident waves busy on average).
-constexpr int EARLY = 32;              // "none" slots per segment that its owner workgroup zero-fills in the prologue
+#ifndef RRT_EARLY
+#define RRT_EARLY 32
+#endif
+constexpr int EARLY = RRT_EARLY;       // "none" slots per segment that its owner workgroup zero-fills in the prologue
 constexpr int Q_CAP = 1024;            // entries staged per batch and workgroup (= its threads)
 struct WgQueue {
   unsigned long long ent[Q_CAP];
@@ -674,9 +686,39 @@ __device__ __forceinline__ void block_excl_scan(const unsigned (&x)[N], unsigned
 // QueueState carries the first index not yet staged and the number of entries before the
 // chunk.  Returns the number staged (<= Q_CAP: the caller sizes the chunk for that).  k_fwd
 // (WITH_EMPTY) stages its share of the "none" list the same way into the zero queue.
+// Which indices of the "none" list a workgroup of k_fwd zero-fills.  The store path of the odd XCDs of an MI355X is
+// ~15 % slower than that of the even ones (tools/ubench/xcc_speed.hip: 21-23 us against 18.4 us for the same 768 KB per
+// workgroup; loads and VALU within 2 %), blocks go to XCDs round-robin (block b on XCD b mod 8 on every box seen), and
+// k_fwd's store stream is bound per XCD: with equal shares the odd XCDs' workgroups finished 2.2 us after the even ones
+// (tools/stamp_fwd.py).  So the list is dealt in rounds of w_odd full rows -- one index per workgroup -- followed by
+// w_even - w_odd half rows for the workgroups with even blockIdx only: they zero-fill w_even tiles for every w_odd of an odd
+// one.  The partition depends on blockIdx alone: were blocks placed differently, only the balance would suffer.
+// w_even = w_odd is the plain interleaved deal (index j n + me).
+struct XcdDeal {
+  unsigned n, me, w_even, w_odd, round;
+  __device__ __forceinline__ XcdDeal(unsigned n_, unsigned me_, unsigned we, unsigned wo) : n(n_), me(me_), w_even(we), w_odd(wo) {
+    if ((n & 1u) || w_even < w_odd || w_odd == 0u) w_even = w_odd = 1u;
+    round = w_odd * n + (w_even - w_odd) * (n / 2);
+  }
+  __device__ __forceinline__ unsigned mine() const { return (me & 1u) ? w_odd : w_even; }   // indices per round
+  // the j-th index this workgroup owns
+  __device__ __forceinline__ unsigned owned(unsigned j) const {
+    const unsigned w = mine(), r = j / w, k = j - r * w;
+    return r * round + (k < w_odd ? k * n + me : w_odd * n + (k - w_odd) * (n / 2) + me / 2);
+  }
+  // how many of its indices lie below x
+  __device__ __forceinline__ unsigned below(unsigned x) const {
+    const unsigned r = x / round, rem = x - r * round;
+    unsigned c = r * mine();
+    if (rem > me) c += min(w_odd, (rem - me + n - 1) / n);
+    if (!(me & 1u) && rem > w_odd * n + me / 2) c += min(w_even - w_odd, (rem - w_odd * n - me / 2 + n / 2 - 1) / (n / 2));
+    return c;
+  }
+};
+
 struct QueueState {
   unsigned base = 0, next = 0;       // "has candidates": entries before the chunk / first index not yet staged
-  unsigned base_e = 0, next_e = 0;   // "none" (k_fwd only)
+  unsigned base_e = 0, j_e = 0;      // "none" (k_fwd only): entries before the chunk / how many of its indices are staged
   unsigned cnt_e = 0;                // "none" entries staged in the current batch
 };
 
@@ -687,7 +729,8 @@ template <bool WITH_EMPTY, class Hook>
 __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const unsigned long long* heavy,
                                                const unsigned long long* empty, uint2 cw, unsigned bin0, unsigned nb,
                                                QueueState& st, int lane, int wave, Hook mid,
-                                               unsigned long long* save, unsigned* save_cnt) {
+                                               unsigned long long* save, unsigned* save_cnt, unsigned zw_even = 1u,
+                                               unsigned zw_odd = 1u) {
   constexpr int N = WITH_EMPTY ? 4 : 3;
   const unsigned t = threadIdx.x, n = gridDim.x;
   unsigned c[N], ex[N], tot[N];
@@ -703,7 +746,8 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
   mid();
   const unsigned end = st.base + tot[0] + tot[1] + tot[2];
   const unsigned end_e = WITH_EMPTY ? st.base_e + tot[N - 1] : 0u;
-  const unsigned g = st.next + t * n, ge = st.next_e + t * n;
+  const XcdDeal zd(n, blockIdx.x, zw_even, zw_odd);
+  const unsigned g = st.next + t * n, ge = WITH_EMPTY ? zd.owned(st.j_e + t) : 0u;
   const bool on = g < end, on_e = WITH_EMPTY && ge < end_e;
   if (__ballot(on || on_e)) {
     unsigned x = on ? g - st.base : 0u;
@@ -714,6 +758,7 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
     unsigned lo = 0, le = 0;       // both binary searches side by side: their LDS reads overlap
 #pragma unroll
     for (unsigned step = Q_CAP / 2; step; step >>= 1) {
+      if (step >= nb) continue;        // (wave-uniform: a step of nb or more cannot stay below nb)
       const unsigned i = lo + step, ie = le + step;
       const unsigned pv = pre[min(i, nb - 1)];
       if (WITH_EMPTY) {
@@ -737,8 +782,8 @@ __device__ __forceinline__ unsigned queue_fill(WgQueue& q, WgZeroQueue* z, const
   st.next += cnt * n;
   st.base = end;
   if (WITH_EMPTY) {
-    st.cnt_e = st.next_e < end_e ? (end_e - st.next_e + n - 1) / n : 0u;
-    st.next_e += st.cnt_e * n;
+    st.cnt_e = zd.below(end_e) - st.j_e;
+    st.j_e += st.cnt_e;
     st.base_e = end_e;
   }
   __syncthreads();
@@ -817,20 +862,23 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
   uint2 cw = threadIdx.x < min(chunk, (unsigned)a.n_bins) ? reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x]
                                                            : make_uint2(0u, 0u);
   unsigned long long early = zero_early_load(a, 0u, min(chunk, (unsigned)a.n_bins));
-  stage_scene(a, s_scene);
+  stage_scene(a, s_scene);          // (ends with the workgroup barrier)
   RRT_STAMP_FWD(5, ~0ull);
 
+  const unsigned lane12 = (unsigned)lane * 12u;
   auto zero_tile = [&](unsigned long long e) {
     int k0; bool multi; long long tile;
     const Tile t = decode_entry(a, e, k0, multi, tile);
+    // (a wave-uniform row address in SGPRs -- one scalar add per row -- plus the lane's 12-byte slot as a 32-bit vector
+    // offset: the saddr form of global_store; as `image + (...) * 3` with the lane folded into a 64-bit vector base, every
+    // row cost two v_mad_u64_u32)
+    char* row = tile_row_ptr(a.image, t);
+    const size_t row_bytes = (size_t)kargs_here()->v.ncols * 12;
     if (lane < t.ncols) {
       const F3 zero = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        if (p < t.nrows) {
-          F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + t.a0 + p) * v.ncols + t.b0) * 3);
-          out[lane] = zero;
-        }
+        if (p < t.nrows) *reinterpret_cast<F3*>(row + p * row_bytes + lane12) = zero;
       }
     }
   };
@@ -844,10 +892,18 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
     return i + count < cnt_e;
   };
 
+  // the head of the workgroup's own "none" segments: stores that need no list work, issued between the scans and the
+  // searches of the deal (right behind the staging barrier, 1.5 us earlier, they made the kernel 0.6 us SLOWER: measured)
+  auto zero_early = [&] {
+    for (unsigned i = wave; i < (Q_CAP / SEG) * EARLY; i += WAVES) {
+      const unsigned long long e = lane_bcast64(s_z.early[i], 0);
+      if (e != ~0ull) zero_tile(e);
+    }
+  };
   int b_cur = -1;
   SceneP sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
   QueueState qs;
-  qs.next = qs.next_e = blockIdx.x;
+  qs.next = blockIdx.x;
   // lds_scene = 2 (a batch of many small scenes): no global deal -- the workgroup takes whole list segments
   // (its own, blockIdx.x + i * gridDim.x), stages the segment's scene and works through the segment's entries
   const bool local = a.lds_scene == 2;
@@ -872,12 +928,8 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
       }
       if (threadIdx.x < (Q_CAP / SEG) * EARLY) s_z.early[threadIdx.x] = early;
       const size_t slot = (size_t)(bin0 / chunk) * gridDim.x + blockIdx.x;
-      cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave, [&] {
-        for (unsigned i = wave; i < (Q_CAP / SEG) * EARLY; i += WAVES) {
-          const unsigned long long e = lane_bcast64(s_z.early[i], 0);
-          if (e != ~0ull) zero_tile(e);
-        }
-      }, a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
+      cnt = queue_fill<true>(s_q, &s_z, a.heavy, a.empty, cw, bin0, nb, qs, lane, wave, zero_early,
+                             a.wgq + slot * Q_CAP, a.wgq_cnt + slot, (unsigned)a.zw_even, (unsigned)a.zw_odd);
       cnt_e = qs.cnt_e;
     }
     const unsigned per = cnt ? (cnt_e + cnt - 1) / cnt : 0;
@@ -982,13 +1034,16 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
       // keeps the address arithmetic down here: hoisted above the sample loop it was spilled.)
       int a0 = t.a0, b0 = t.b0;
       asm volatile("" : "+s"(a0), "+s"(b0));
+      Tile ts = t;
+      ts.a0 = a0; ts.b0 = b0;
+      char* row = tile_row_ptr(a.image, ts);         // (scalar base + 32-bit lane offset, as in zero_tile)
+      const size_t row_bytes = (size_t)kargs_here()->v.ncols * 12;
       if (lane < t.ncols) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           if (p < t.nrows) {
-            F3* out = reinterpret_cast<F3*>(a.image + (((size_t)t.b * v.rows + a0 + p) * v.ncols + b0) * 3);
             F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
-            out[lane] = val;
+            *reinterpret_cast<F3*>(row + p * row_bytes + lane12) = val;
           }
         }
       }
@@ -1009,6 +1064,8 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
     while (more_zero) more_zero = zero_fill(2, cnt_e);
   }
   RRT_STAMP_FWD(2, ~0ull);
+  // (diagnostic builds) the XCD this wave ran on: HW_REG_XCC_ID[3:0]
+  RRT_STAMP_FWD(3, 1 + (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15));
 }
 
 // --------------------------------------------------------------- backward --
@@ -1742,6 +1799,8 @@ struct Geometry {
 struct Tune {
   int P = 0;              // RRT_TUNE_P=1|2|4: rows per wave tile
   int fwd_wgs = 0, bwd_wgs = 0, chunk = 0;
+  int zw_even = 6, zw_odd = 5;   // RRT_TUNE_ZW=even:odd  shares of k_fwd's zero-filled tiles by blockIdx parity (XcdDeal;
+                                 // sweep 1:1 ... 4:3, profiles/r03_xcd_store_asymmetry.txt: flat between 7:6 and 5:4)
   bool no_lds = false, no_saved = false;
 };
 Tune g_tune;
@@ -1753,6 +1812,10 @@ void read_tune(Tune& x) {
   x.fwd_wgs = num("RRT_TUNE_FWD_WGS");
   x.bwd_wgs = num("RRT_TUNE_BWD_WGS");
   x.chunk = num("RRT_TUNE_CHUNK");
+  if (const char* zw = getenv("RRT_TUNE_ZW")) {
+    int we = 0, wo = 0;
+    if (sscanf(zw, "%d:%d", &we, &wo) == 2 && wo >= 1 && we >= wo && we <= 64) { x.zw_even = we; x.zw_odd = wo; }
+  }
   x.no_lds = getenv("RRT_TUNE_NOLDS") != nullptr;
   x.no_saved = getenv("RRT_TUNE_NOSAVED") != nullptr;
 }
@@ -1888,6 +1951,10 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.wgq_cnt = (unsigned*)(base + g.wgq_cnt_off);
   a.use_saved = 0;
   a.chunk = g.chunk;
+  // weighted shares only where a favoured workgroup's share surely fits its zero queue (average share <= Q_CAP / 2)
+  const bool weigh = (long long)g.n_bins * SEG * 2 <= (long long)Q_CAP * g.blocks_fwd && !(g.blocks_fwd & 1u);
+  a.zw_even = weigh ? tune().zw_even : 1;
+  a.zw_odd = weigh ? tune().zw_odd : 1;
   a.n_waves = 0;
   a.jitter = v->jitter_mode == RRT_JITTER_EXPLICIT ? v->jitter : nullptr;
   a.image = nullptr;

@@ -774,6 +774,40 @@ def test_several_queue_batches(dev, chunk, monkeypatch):
     assert_grad_close(got[1], ow, "g_w2o")
 
 
+@pytest.mark.parametrize("shares,chunk", [("1:1", 0), ("3:1", 0), ("64:1", 0), ("7:5", 0), ("5:2", 3)])
+def test_weighted_zero_tile_shares(dev, shares, chunk, monkeypatch):
+    """k_fwd deals the tiles it only zero-fills with different shares for workgroups of even and odd blockIdx (the
+    odd XCDs of an MI355X store ~15 % slower: DESIGN.md section 5; default 6:5).  Whatever the shares -- also
+    across several queue batches -- every tile is written exactly once: the image equals the default's bit for
+    bit, background included, and the gradients agree."""
+    from rrt import synthetic, _native
+    w2o, mat, light, kinds = synthetic.random_spheres(6, seed=4)
+    w2o = w2o.copy()
+    w2o[:, :, :3] *= 2.0                       # smaller spheres: most tiles have no candidate
+    w2o[:, :, 3] *= 2.0
+    G = np.random.RandomState(3).randn(1024, 2048, 3)
+    kw = dict(x_dims=1024, y_dims=2048, antialias_samples=1)     # 8192 tiles: 256 workgroups, 32 list segments
+    ref = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    assert (ref[0].max(-1) > 0).mean() < 0.5
+    monkeypatch.setenv("RRT_TUNE_ZW", shares)
+    if chunk:
+        monkeypatch.setenv("RRT_TUNE_CHUNK", str(chunk))
+    _native.lib().rrt_debug_reload_tuning()
+    try:
+        # poison the block the caching allocator hands to the render's output: an unwritten tile would read NaN
+        poison = torch.full((1024, 2048, 3), float("nan"), device=dev)
+        del poison
+        got = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw)
+    finally:
+        monkeypatch.delenv("RRT_TUNE_ZW")
+        if chunk:
+            monkeypatch.delenv("RRT_TUNE_CHUNK")
+        _native.lib().rrt_debug_reload_tuning()
+    assert np.array_equal(got[0], ref[0])
+    for a, b, what in zip(got[1:], ref[1:], ("g_w2o", "g_material", "g_light")):
+        assert_grad_close(a, b, what, rtol=1e-4)
+
+
 def test_backward_with_and_without_saved_queues(dev, monkeypatch):
     """a backward on the forward's setup reads the queue batches the forward
     dealt; RRT_TUNE_NOSAVED makes it deal them again -- same gradients"""

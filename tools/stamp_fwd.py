@@ -16,7 +16,7 @@ PKG = os.path.join(REPO, "reversible-raytracer_amd")
 OUT = os.path.join(REPO, "gpurun_out", "librrt_hip_stamps.so")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-                       "-DRRT_STAMPS", "-fno-slp-vectorize", "-I", os.path.join(REPO, "include"), "-I", os.path.join(PKG, "csrc"),
+                       "-DRRT_STAMPS", "-fno-slp-vectorize"] + os.environ.get("RRT_STAMP_FLAGS", "").split() + [ "-I", os.path.join(REPO, "include"), "-I", os.path.join(PKG, "csrc"),
                        os.environ.get("RRT_STAMP_SRC", os.path.join(PKG, "csrc", "rrt_kernels.hip")), "-o", OUT])
 os.environ["RRT_LIB"] = OUT
 sys.path.insert(0, PKG)
@@ -41,6 +41,8 @@ assert job.L.rrt_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
 job.fwd()
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().astype(np.float64)
+gw_all = np.arange(len(st))
+gw_all = gw_all[st[:, 0] != 0]
 st = st[st[:, 0] != 0]
 t0 = st[:, 0].min()
 start, pro, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, (st[:, 2] - t0) / 100.0     # us (100 MHz)
@@ -71,3 +73,21 @@ for i in range(nb):
     lo, hi = edges[i], edges[i + 1]
     prof.append(np.clip(np.minimum(end, hi) - np.maximum(start, lo), 0, None).sum() / (hi - lo) / 1024.0)
 print("resident waves per SIMD over %d slices of the span: %s" % (nb, " ".join("%.1f" % x for x in prof)))
+
+# hardware XCD (HW_REG_XCC_ID, slot 3) against the block index
+xcc = st[:, 3] - 1
+print("XCC_ID of blocks 0..15:", [int(xcc[blk_i * 16]) if blk_i * 16 < len(xcc) else -1 for blk_i in range(16)])
+for x in range(8):
+    sel = xcc == x
+    if sel.sum():
+        print("XCC %d: %4d waves, blocks mod 8 = %s, wave end median %.1f p90 %.1f max %.1f us" % (
+            x, sel.sum(), sorted(set(((gw_all[sel] // 16) % 8).tolist())), np.median(end[sel]), np.percentile(end[sel], 90), end[sel].max()))
+# by XCD (workgroups are dealt round-robin over the 8 XCDs: blocks b and b + 8 share one) and by workgroup
+blk = gw_all // 16
+for x in range(8):
+    sel = blk % 8 == x
+    print("blocks = %d mod 8: wave end median %.1f p90 %.1f max %.1f us" % (x, np.median(end[sel]), np.percentile(end[sel], 90), end[sel].max()))
+wg_end = np.array([end[blk == b].max() for b in np.unique(blk)])
+wg_first = np.array([end[blk == b].min() for b in np.unique(blk)])
+print("workgroup end (last wave): p10 %.1f median %.1f p90 %.1f max %.1f; first wave out of a workgroup: median %.1f" % (
+    np.percentile(wg_end, 10), np.median(wg_end), np.percentile(wg_end, 90), wg_end.max(), np.median(wg_first)))
