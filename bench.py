@@ -345,8 +345,10 @@ def main():
         # counters of the same command (rocprofv3 --pmc, tools/profile_round.sh -> profiles/): HBM bytes and VALU
         # wave-instructions per launch; VALU issue peak from tools/ubench/issue_probe2.hip
         prof = None
-        ppath = os.path.join(REPO, "profiles", "r02_counters.json")
-        if os.path.exists(ppath) and world == 1:
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_counters.json")))     # the latest round's
+        ppath = cands[-1] if cands else ""
+        if ppath and world == 1:
             pj = json.load(open(ppath))
             pw = pj["workload"]
             if (pw["size"], pw["spheres"], pw["aa"]) == (args.size, args.spheres, args.aa):
@@ -361,7 +363,7 @@ def main():
             if prof is not None:
                 k = prof[name]
                 r["traffic"] = k["hbm_bytes"]
-                r["traffic_source"] = "from_profile: profiles/r02_counters.json (%s)" % prof["source"]
+                r["traffic_source"] = "from_profile: profiles/%s (%s)" % (os.path.basename(ppath), prof["source"])
                 # rocprofv3's own begin-to-end duration of the dispatch; `us` (HIP events) also holds the launch gap
                 r["us_kernel_trace_from_profile"] = k["avg_us_kernel_trace"]
                 hbm_real = k["hbm_bytes"] / t / 1e9

@@ -145,8 +145,14 @@ struct KArgs {
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
-  float* acc;                     // bwd: [B][S][ACC_STRIDE]
+  float* acc;                     // bwd: [acc_repl][B][S][ACC_STRIDE]
+  int acc_repl;                   // copies of the accumulator rows: workgroup b of k_bwd adds to copy b mod acc_repl and
+                                  // k_finalize sums the copies.  Same-line float atomics serialise at ~13 ns each: with one
+                                  // copy all 256 workgroups queue on every shape's line -- 3.5 us at the end of k_bwd
 };
+__device__ __forceinline__ float* acc_copy(const KArgs& a) {      // this workgroup's copy of the accumulator rows
+  return a.acc + (size_t)(blockIdx.x % (unsigned)a.acc_repl) * ((size_t)a.B * a.S * ACC_STRIDE);
+}
 
 // The render kernels carry ~170 scalar values over their tile loops and spill them into vector lanes; every use is then a
 // v_readlane, a VALU instruction of the slow class.  What a tile needs of the kernel arguments only at its start or end is
@@ -492,6 +498,16 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
     region = tile_cone<float>(a.v, i0, i1, j0, j1);
   }
   if (owner && tid == 0) pack_header<float, float>(cam, pa.light, pa.hdr + (size_t)b * HDR_STRIDE);
+  {
+    // the scene's gradient-accumulator rows, every copy: a slice per block of the scene (k_finalize leaves them zeroed
+    // too; this covers a fresh workspace)
+    const int per = a.S * (ACC_STRIDE / 4), total = per * a.acc_repl;
+    const int nblk = bx_n * by_n, me = by * bx_n + bx, slice = (total + nblk - 1) / nblk;
+    for (int i = me * slice + tid; i < min(total, (me + 1) * slice); i += blockDim.x) {
+      const int r = i / per, j = i - r * per;
+      reinterpret_cast<float4*>(pa.acc + ((size_t)r * a.B + b) * a.S * ACC_STRIDE)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 
   int n = 0;                                     // survivors so far (uniform)
   for (int k0 = 0; k0 < a.S; k0 += 256) {
@@ -505,12 +521,8 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
       ball = make_float4(rec[PS_CULL_C], rec[PS_CULL_C + 1], rec[PS_CULL_C + 2], rec[PS_CULL_R]);
       if (owner) {
         float4* dst = reinterpret_cast<float4*>(pa.ps + ((size_t)b * a.S + k) * PS_STRIDE);
-        float4* row = reinterpret_cast<float4*>(pa.acc + ((size_t)b * a.S + k) * ACC_STRIDE);
 #pragma unroll
-        for (int q = 0; q < PS_STRIDE / 4; ++q) {
-          dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-          row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int q = 0; q < PS_STRIDE / 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
       }
       float cc[3] = {ball.x, ball.y, ball.z};
       c = nocull || cone_may_hit<float>(region, cc, ball.w);
@@ -1281,7 +1293,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
   // (2) the accumulator atomic held back from the previous tile
   if (w.held) {
     if (lane < ACC_USED)
-      __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val,
+      __hip_atomic_fetch_add(acc_copy(a) + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     w.held = false;
   }
@@ -1470,7 +1482,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
           mine_val = (lane == n) ? bc : mine_val;
         }
         if (w.held && lane < ACC_USED)
-          __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val,
+          __hip_atomic_fetch_add(acc_copy(a) + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w.held = true; w.held_k = k; w.held_b = t.b; w.held_val = mine_val;
       }
@@ -1545,7 +1557,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
         for (int i = threadIdx.x; i < a.S * ACC_STRIDE; i += blockDim.x) {
           const float x = s_acc[i];
           if ((i & (ACC_STRIDE - 1)) < ACC_USED && x != 0.f)
-            __hip_atomic_fetch_add(a.acc + (size_t)bp * a.S * ACC_STRIDE + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(acc_copy(a) + (size_t)bp * a.S * ACC_STRIDE + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
       }
@@ -1595,7 +1607,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
       bwd_tile<P, SHADER, SPEC, JC, TR, false, SH>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
   }
   if (w.held && lane < ACC_USED)
-    __hip_atomic_fetch_add(a.acc + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val, __ATOMIC_RELAXED,
+    __hip_atomic_fetch_add(acc_copy(a) + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
   if (a.lds_scene) {
     __syncthreads();                 // every wave of the workgroup is done adding
@@ -1603,7 +1615,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     const unsigned last = local && blockIdx.x < (unsigned)a.n_bins
                               ? blockIdx.x + ((unsigned)a.n_bins - 1u - blockIdx.x) / gridDim.x * gridDim.x : 0u;
     const int n = local ? (blockIdx.x < (unsigned)a.n_bins ? a.S * ACC_STRIDE : 0) : a.B * a.S * ACC_STRIDE;
-    float* dst = a.acc + (local ? (size_t)(last / (unsigned)a.bins_per_scene) * a.S * ACC_STRIDE : 0);
+    float* dst = acc_copy(a) + (local ? (size_t)(last / (unsigned)a.bins_per_scene) * a.S * ACC_STRIDE : 0);
     // (every workgroup starts at a different shape row: they finish together and would otherwise all queue on row 0)
     const int rot = n ? (int)((blockIdx.x * 5u * ACC_STRIDE) % (unsigned)n) : 0;
     for (int i0 = threadIdx.x; i0 < n; i0 += blockDim.x) {
@@ -1617,98 +1629,86 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
 }
 
 // --------------------------------------------------------------- finalize --
-// One block; the work is tiny (B*S rows of 32 floats) and the kernel is pure latency, so
-// the common case -- every scene has its own transforms and materials, or there is one scene
-// -- reads each accumulator row ONCE (float4 loads, all in flight together), derives all three
-// gradients from it, re-zeroes it, and sums the light terms with DPP wave sums and one
-// barrier.  Shared (stride-0) parameters take the general path below.  Leaves the accumulator
-// rows zeroed for the next backward.
+// One block; the work is tiny (B*S rows of 32 floats) and the kernel is pure latency.  Per batch of 256
+// rows: all threads sum the R copies of the rows (k_bwd's workgroups add to copy blockIdx mod R), float4
+// by float4 with the R loads of a thread in flight together, leave the sums in LDS and the copies zeroed
+// for the next backward; then a thread per row derives all three gradients from its row -- stored directly
+// where every scene has its own transforms and materials (or there is one scene), summed over the scenes
+// through LDS (ds_add_f32) for shared (stride-0) parameters -- and the light terms are summed with DPP
+// wave sums and one barrier.  Scenes of more than FIN_S shapes with shared parameters keep serial loops
+// (they run with one copy).
+constexpr int FIN_S = 256, FIN_ROWS = 256;
+template <int R>
 __global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, const float* hdr, const float* mat,
                                                   long long mat_bs, const float* light, long long w2o_bs,
                                                   float* g_w2o, float* g_mat, float* g_light) {
   __shared__ float s_red[256][6];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Bw = w2o_bs ? B : 1, Bm = mat_bs ? B : 1;
-  if (B == 1 || (w2o_bs && mat_bs)) {
-    float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int idx = tid; idx < B * S; idx += blockDim.x) {
-      const int b = idx / S, k = idx - b * S;
-      float row[ACC_STRIDE];
-      float4* src = reinterpret_cast<float4*>(acc + (size_t)idx * ACC_STRIDE);
-#pragma unroll
-      for (int q = 0; q < ACC_STRIDE / 4; ++q) {
-        const float4 x = src[q];
-        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
-      }
-#pragma unroll
-      for (int q = 0; q < ACC_STRIDE / 4; ++q) src[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g_w2o) {
-        float gw[12];
-        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
-        finalize_w2o<float>(row, hdr + (size_t)b * HDR_STRIDE, gw);
-        for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
-      }
-      if (g_mat) {
-        float gm[7];
-        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
-        finalize_material<float>(row, light, gm);
-        for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
-      }
-      if (g_light) finalize_light_accum<float>(row, mat + b * mat_bs + 7 * k, gl);
-    }
-    if (g_light) {
-#pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        const float tot = wave_sum_to_lane63(gl[n]);
-        if (lane == 63) s_red[wave][n] = tot;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        float g[6];
-        for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
-        finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
-        for (int n = 0; n < 6; ++n) g_light[n] = g[n];
-      }
-    }
-    return;
-  }
-  // Shared (batch stride 0) transforms or materials: their gradient is the sum over the scenes.  Every
-  // thread chains one (scene, shape) row and adds it to LDS sums (a serial loop over the scenes per shape
-  // made the 256-scene orbit batch spend 30 us here); beyond FIN_S shapes the serial loops remain.
-  constexpr int FIN_S = 256;
+  __shared__ float4 s_rows[FIN_ROWS * (ACC_STRIDE / 4)];
   __shared__ float s_gw[FIN_S * 12];
   __shared__ float s_gm[FIN_S * 7];
-  if (S <= FIN_S) {
-    if (g_w2o && !w2o_bs)
-      for (int i = tid; i < S * 12; i += blockDim.x) s_gw[i] = 0.f;
-    if (g_mat && !mat_bs)
-      for (int i = tid; i < S * 7; i += blockDim.x) s_gm[i] = 0.f;
-    __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Bw = w2o_bs ? B : 1, Bm = mat_bs ? B : 1;
+  const int n_rows = B * S;
+  const bool own = B == 1 || (w2o_bs && mat_bs);           // nothing is summed over the scenes
+  if (own || S <= FIN_S) {
+    if (!own) {
+      if (g_w2o && !w2o_bs)
+        for (int i = tid; i < S * 12; i += blockDim.x) s_gw[i] = 0.f;
+      if (g_mat && !mat_bs)
+        for (int i = tid; i < S * 7; i += blockDim.x) s_gm[i] = 0.f;
+    }
     float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int idx = tid; idx < B * S; idx += blockDim.x) {
-      const int b = idx / S, k = idx - b * S;
-      float row[ACC_STRIDE];
-      const float4* src = reinterpret_cast<const float4*>(acc + (size_t)idx * ACC_STRIDE);
+    const size_t copy4 = (size_t)n_rows * (ACC_STRIDE / 4);             // float4s per copy
+    for (int base = 0; base < n_rows; base += FIN_ROWS) {
+      const int nb = min(FIN_ROWS, n_rows - base);
+      if (base) __syncthreads();                                        // the previous batch's rows are consumed
+      // what this thread's row will need besides its sums -- camera rows, light intensity, the shape's colour -- is
+      // requested here, together with the sums: behind the barrier it would be a second memory round trip
+      float hc[HDR_STRIDE], li[6], col[7];
+      if (tid < nb) {
+        const int idx = base + tid, b = idx / S, k = idx - b * S;
 #pragma unroll
-      for (int q = 0; q < ACC_STRIDE / 4; ++q) {
-        const float4 x = src[q];
-        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+        for (int n = 0; n < 12; ++n) hc[HDR_CAM + n] = hdr[(size_t)b * HDR_STRIDE + HDR_CAM + n];     // camera 9 + origin 3
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { li[3 + n] = light[3 + n]; col[n] = mat[b * mat_bs + 7 * k + n]; }
       }
-      if (g_w2o) {
-        float gw[12];
-        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
-        finalize_w2o<float>(row, hdr + (size_t)b * HDR_STRIDE, gw);
-        if (w2o_bs) { for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n]; }
-        else { for (int n = 0; n < 12; ++n) atomicAdd(&s_gw[k * 12 + n], gw[n]); }
+      float4* src = reinterpret_cast<float4*>(acc) + (size_t)base * (ACC_STRIDE / 4);
+      for (int c = tid; c < nb * (ACC_STRIDE / 4); c += blockDim.x) {
+        float4 x[R];                                                    // (R is a template parameter: the loads leave together)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = src[(size_t)r * copy4 + c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) src[(size_t)r * copy4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sum = x[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) { sum.x += x[r].x; sum.y += x[r].y; sum.z += x[r].z; sum.w += x[r].w; }
+        s_rows[c] = sum;
       }
-      if (g_mat) {
-        float gm[7];
-        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
-        finalize_material<float>(row, light, gm);
-        if (mat_bs) { for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n]; }
-        else { for (int n = 0; n < 7; ++n) atomicAdd(&s_gm[k * 7 + n], gm[n]); }
+      __syncthreads();
+      if (tid < nb) {
+        const int idx = base + tid, b = idx / S, k = idx - b * S;
+        float row[ACC_STRIDE];
+#pragma unroll
+        for (int q = 0; q < ACC_STRIDE / 4; ++q) {
+          const float4 x = s_rows[tid * (ACC_STRIDE / 4) + q];
+          row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+        }
+        if (g_w2o) {
+          float gw[12];
+          for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+          finalize_w2o<float>(row, hc, gw);
+          if (own || w2o_bs) { for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n]; }
+          else { for (int n = 0; n < 12; ++n) atomicAdd(&s_gw[k * 12 + n], gw[n]); }
+        }
+        if (g_mat) {
+          float gm[7];
+          for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+          finalize_material<float>(row, li, gm);
+          if (own || mat_bs) { for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n]; }
+          else { for (int n = 0; n < 7; ++n) atomicAdd(&s_gm[k * 7 + n], gm[n]); }
+        }
+        if (g_light) finalize_light_accum<float>(row, col, gl);
       }
-      if (g_light) finalize_light_accum<float>(row, mat + b * mat_bs + 7 * k, gl);
     }
     if (g_light) {
 #pragma unroll
@@ -1718,56 +1718,59 @@ __global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, cons
       }
     }
     __syncthreads();
-    if (g_w2o && !w2o_bs)
-      for (int i = tid; i < S * 12; i += blockDim.x) g_w2o[i] = s_gw[i];
-    if (g_mat && !mat_bs)
-      for (int i = tid; i < S * 7; i += blockDim.x) g_mat[i] = s_gm[i];
+    if (!own) {
+      if (g_w2o && !w2o_bs)
+        for (int i = tid; i < S * 12; i += blockDim.x) g_w2o[i] = s_gw[i];
+      if (g_mat && !mat_bs)
+        for (int i = tid; i < S * 7; i += blockDim.x) g_mat[i] = s_gm[i];
+    }
     if (g_light && tid == 0) {
       float g[6];
       for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
       finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
       for (int n = 0; n < 6; ++n) g_light[n] = g[n];
     }
-  } else {
-    if (g_w2o) {
-      for (int idx = tid; idx < Bw * S; idx += blockDim.x) {
-        int bw = idx / S, k = idx - bw * S;
-        float gw[12];
-        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
-        int blo = w2o_bs ? bw : 0, bhi = w2o_bs ? bw + 1 : B;
-        for (int b = blo; b < bhi; ++b)
-          finalize_w2o<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, hdr + (size_t)b * HDR_STRIDE, gw);
-        for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
-      }
+    return;
+  }
+  // shared parameters and more than FIN_S shapes: serial loops over the scenes (one copy of the rows: R == 1)
+  if (g_w2o) {
+    for (int idx = tid; idx < Bw * S; idx += blockDim.x) {
+      int bw = idx / S, k = idx - bw * S;
+      float gw[12];
+      for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+      int blo = w2o_bs ? bw : 0, bhi = w2o_bs ? bw + 1 : B;
+      for (int b = blo; b < bhi; ++b)
+        finalize_w2o<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, hdr + (size_t)b * HDR_STRIDE, gw);
+      for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
     }
-    if (g_mat) {
-      for (int idx = tid; idx < Bm * S; idx += blockDim.x) {
-        int bm = idx / S, k = idx - bm * S;
-        float gm[7];
-        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
-        int blo = mat_bs ? bm : 0, bhi = mat_bs ? bm + 1 : B;
-        for (int b = blo; b < bhi; ++b) finalize_material<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, light, gm);
-        for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
-      }
+  }
+  if (g_mat) {
+    for (int idx = tid; idx < Bm * S; idx += blockDim.x) {
+      int bm = idx / S, k = idx - bm * S;
+      float gm[7];
+      for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+      int blo = mat_bs ? bm : 0, bhi = mat_bs ? bm + 1 : B;
+      for (int b = blo; b < bhi; ++b) finalize_material<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, light, gm);
+      for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
     }
-    if (g_light) {
-      float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int idx = tid; idx < B * S; idx += blockDim.x) {
-        int b = idx / S, k = idx - b * S;
-        finalize_light_accum<float>(acc + (size_t)idx * ACC_STRIDE, mat + b * mat_bs + 7 * k, gl);
-      }
+  }
+  if (g_light) {
+    float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < B * S; idx += blockDim.x) {
+      int b = idx / S, k = idx - b * S;
+      finalize_light_accum<float>(acc + (size_t)idx * ACC_STRIDE, mat + b * mat_bs + 7 * k, gl);
+    }
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        const float tot = wave_sum_to_lane63(gl[n]);
-        if (lane == 63) s_red[wave][n] = tot;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        float g[6];
-        for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
-        finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
-        for (int n = 0; n < 6; ++n) g_light[n] = g[n];
-      }
+    for (int n = 0; n < 6; ++n) {
+      const float tot = wave_sum_to_lane63(gl[n]);
+      if (lane == 63) s_red[wave][n] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float g[6];
+      for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
+      finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
+      for (int n = 0; n < 6; ++n) g_light[n] = g[n];
     }
   }
   __syncthreads();                                   // every read of acc is done
@@ -1792,6 +1795,7 @@ struct Geometry {
   unsigned blocks_fwd, blocks_bwd;   // persistent grids of the render kernels
   int lds_mode;                      // KArgs::lds_scene
   int chunk;                         // list segments per queue batch
+  int acc_repl;                      // copies of the gradient-accumulator rows (KArgs::acc_repl)
 };
 
 // RRT_TUNE_* environment variables (tuning experiments and tests only), read ONCE per process -- not on
@@ -1799,6 +1803,7 @@ struct Geometry {
 struct Tune {
   int P = 0;              // RRT_TUNE_P=1|2|4: rows per wave tile
   int fwd_wgs = 0, bwd_wgs = 0, chunk = 0;
+  int repl = 4;                  // RRT_TUNE_REPL=1|2|4|8: copies of the gradient-accumulator rows (KArgs::acc_repl)
   int zw_even = 6, zw_odd = 5;   // RRT_TUNE_ZW=even:odd  shares of k_fwd's zero-filled tiles by blockIdx parity (XcdDeal;
                                  // sweep 1:1 ... 4:3, profiles/r03_xcd_store_asymmetry.txt: flat between 7:6 and 5:4)
   bool no_lds = false, no_saved = false;
@@ -1812,6 +1817,7 @@ void read_tune(Tune& x) {
   x.fwd_wgs = num("RRT_TUNE_FWD_WGS");
   x.bwd_wgs = num("RRT_TUNE_BWD_WGS");
   x.chunk = num("RRT_TUNE_CHUNK");
+  if (getenv("RRT_TUNE_REPL")) { const int r = num("RRT_TUNE_REPL"); x.repl = r >= 8 ? 8 : (r >= 4 ? 4 : (r >= 2 ? 2 : 1)); }
   if (const char* zw = getenv("RRT_TUNE_ZW")) {
     int we = 0, wo = 0;
     if (sscanf(zw, "%d:%d", &we, &wo) == 2 && wo >= 1 && we >= wo && we <= 64) { x.zw_even = we; x.zw_odd = wo; }
@@ -1864,7 +1870,10 @@ Geometry geometry_of(const rrt_scene* s, const rrt_view* v) {
   g.hdr_off = g.ps_off + n_shapes * PS_STRIDE * sizeof(float);
   g.acc_off = g.hdr_off + (size_t)s->B * HDR_STRIDE * sizeof(float);
   g.n_bins = (long long)((g.tiles_x + BIN_RX - 1) / BIN_RX) * ((g.tiles_y + BIN_RY - 1) / BIN_RY) * s->B;
-  g.counts_off = align_up(g.acc_off + n_shapes * ACC_STRIDE * sizeof(float), 16);
+  // copies of the accumulator rows: where ALL of k_bwd's workgroups add to every row at the end of the kernel (LDS
+  // accumulators for the whole batch, lds_mode 1 -- decided below from the same numbers) and k_finalize sums rows through LDS
+  g.acc_repl = (!tune().no_lds && (long long)s->B * s->S <= LDS_RECS && s->S <= 256) ? tune().repl : 1;
+  g.counts_off = align_up(g.acc_off + (size_t)g.acc_repl * n_shapes * ACC_STRIDE * sizeof(float), 16);
   g.mask_off = align_up(g.counts_off + (size_t)g.n_bins * 2 * sizeof(unsigned), 16);
   g.heavy_off = align_up(g.mask_off + (size_t)g.n_tiles * g.nwords * sizeof(unsigned long long), 16);
   g.empty_off = g.heavy_off + (size_t)g.n_bins * SEG * sizeof(unsigned long long);
@@ -1940,6 +1949,7 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.ps = (const float*)(base + g.ps_off);
   a.hdr = (const float*)(base + g.hdr_off);
   a.acc = (float*)(base + g.acc_off);
+  a.acc_repl = g.acc_repl;
   a.mask = (const unsigned long long*)(base + g.mask_off);
   a.heavy = (const unsigned long long*)(base + g.heavy_off);
   a.empty = (const unsigned long long*)(base + g.empty_off);
@@ -2127,9 +2137,14 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
     if (e != hipSuccess) return hip_fail(e);
   }
   if (v->flags & RRT_FLAG_SKIP_FINALIZE) return RRT_OK;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, s->S, s->B, a.acc, a.hdr, s->material,
-                     (long long)s->material_bstride, s->light, (long long)s->w2o_bstride, g_w2o, g_material,
-                     g_light);
+#define RRT_LAUNCH_FINALIZE(R)                                                                                       \
+  hipLaunchKernelGGL(k_finalize<R>, dim3(1), dim3(256), 0, st, s->S, s->B, a.acc, a.hdr, s->material,                  \
+                     (long long)s->material_bstride, s->light, (long long)s->w2o_bstride, g_w2o, g_material, g_light)
+  if (g.acc_repl == 8) RRT_LAUNCH_FINALIZE(8);
+  else if (g.acc_repl == 4) RRT_LAUNCH_FINALIZE(4);
+  else if (g.acc_repl == 2) RRT_LAUNCH_FINALIZE(2);
+  else RRT_LAUNCH_FINALIZE(1);
+#undef RRT_LAUNCH_FINALIZE
   e = hipGetLastError();
   return e == hipSuccess ? RRT_OK : hip_fail(e);
 }
