@@ -1778,6 +1778,166 @@ __global__ __launch_bounds__(256) void k_finalize(int S, int B, float* acc, cons
     reinterpret_cast<float4*>(acc)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// The single-copy form (R = 1: batches of many small scenes, scenes too big for the LDS accumulators): every row is read
+// ONCE straight from memory (float4 loads, all in flight together) -- no LDS hop, all row batches' loads in flight at once
+// (through the staged form above the 512 rows of the 256-scene orbit batch took 12.8 instead of 8.2 us).
+// One block; the work is tiny (B*S rows of 32 floats) and the kernel is pure latency, so
+// the common case -- every scene has its own transforms and materials, or there is one scene
+// -- reads each accumulator row ONCE (float4 loads, all in flight together), derives all three
+// gradients from it, re-zeroes it, and sums the light terms with DPP wave sums and one
+// barrier.  Shared (stride-0) parameters take the general path below.  Leaves the accumulator
+// rows zeroed for the next backward.
+__global__ __launch_bounds__(256) void k_finalize_one(int S, int B, float* acc, const float* hdr, const float* mat,
+                                                  long long mat_bs, const float* light, long long w2o_bs,
+                                                  float* g_w2o, float* g_mat, float* g_light) {
+  __shared__ float s_red[256][6];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Bw = w2o_bs ? B : 1, Bm = mat_bs ? B : 1;
+  if (B == 1 || (w2o_bs && mat_bs)) {
+    float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < B * S; idx += blockDim.x) {
+      const int b = idx / S, k = idx - b * S;
+      float row[ACC_STRIDE];
+      float4* src = reinterpret_cast<float4*>(acc + (size_t)idx * ACC_STRIDE);
+#pragma unroll
+      for (int q = 0; q < ACC_STRIDE / 4; ++q) {
+        const float4 x = src[q];
+        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+      }
+#pragma unroll
+      for (int q = 0; q < ACC_STRIDE / 4; ++q) src[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g_w2o) {
+        float gw[12];
+        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+        finalize_w2o<float>(row, hdr + (size_t)b * HDR_STRIDE, gw);
+        for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
+      }
+      if (g_mat) {
+        float gm[7];
+        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+        finalize_material<float>(row, light, gm);
+        for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
+      }
+      if (g_light) finalize_light_accum<float>(row, mat + b * mat_bs + 7 * k, gl);
+    }
+    if (g_light) {
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const float tot = wave_sum_to_lane63(gl[n]);
+        if (lane == 63) s_red[wave][n] = tot;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float g[6];
+        for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
+        finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
+        for (int n = 0; n < 6; ++n) g_light[n] = g[n];
+      }
+    }
+    return;
+  }
+  // Shared (batch stride 0) transforms or materials: their gradient is the sum over the scenes.  Every
+  // thread chains one (scene, shape) row and adds it to LDS sums (a serial loop over the scenes per shape
+  // made the 256-scene orbit batch spend 30 us here); beyond FIN_S shapes the serial loops remain.
+  __shared__ float s_gw[FIN_S * 12];
+  __shared__ float s_gm[FIN_S * 7];
+  if (S <= FIN_S) {
+    if (g_w2o && !w2o_bs)
+      for (int i = tid; i < S * 12; i += blockDim.x) s_gw[i] = 0.f;
+    if (g_mat && !mat_bs)
+      for (int i = tid; i < S * 7; i += blockDim.x) s_gm[i] = 0.f;
+    __syncthreads();
+    float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < B * S; idx += blockDim.x) {
+      const int b = idx / S, k = idx - b * S;
+      float row[ACC_STRIDE];
+      const float4* src = reinterpret_cast<const float4*>(acc + (size_t)idx * ACC_STRIDE);
+#pragma unroll
+      for (int q = 0; q < ACC_STRIDE / 4; ++q) {
+        const float4 x = src[q];
+        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+      }
+      if (g_w2o) {
+        float gw[12];
+        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+        finalize_w2o<float>(row, hdr + (size_t)b * HDR_STRIDE, gw);
+        if (w2o_bs) { for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n]; }
+        else { for (int n = 0; n < 12; ++n) atomicAdd(&s_gw[k * 12 + n], gw[n]); }
+      }
+      if (g_mat) {
+        float gm[7];
+        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+        finalize_material<float>(row, light, gm);
+        if (mat_bs) { for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n]; }
+        else { for (int n = 0; n < 7; ++n) atomicAdd(&s_gm[k * 7 + n], gm[n]); }
+      }
+      if (g_light) finalize_light_accum<float>(row, mat + b * mat_bs + 7 * k, gl);
+    }
+    if (g_light) {
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const float tot = wave_sum_to_lane63(gl[n]);
+        if (lane == 63) s_red[wave][n] = tot;
+      }
+    }
+    __syncthreads();
+    if (g_w2o && !w2o_bs)
+      for (int i = tid; i < S * 12; i += blockDim.x) g_w2o[i] = s_gw[i];
+    if (g_mat && !mat_bs)
+      for (int i = tid; i < S * 7; i += blockDim.x) g_mat[i] = s_gm[i];
+    if (g_light && tid == 0) {
+      float g[6];
+      for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
+      finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
+      for (int n = 0; n < 6; ++n) g_light[n] = g[n];
+    }
+  } else {
+    if (g_w2o) {
+      for (int idx = tid; idx < Bw * S; idx += blockDim.x) {
+        int bw = idx / S, k = idx - bw * S;
+        float gw[12];
+        for (int n = 0; n < 12; ++n) gw[n] = 0.f;
+        int blo = w2o_bs ? bw : 0, bhi = w2o_bs ? bw + 1 : B;
+        for (int b = blo; b < bhi; ++b)
+          finalize_w2o<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, hdr + (size_t)b * HDR_STRIDE, gw);
+        for (int n = 0; n < 12; ++n) g_w2o[(size_t)idx * 12 + n] = gw[n];
+      }
+    }
+    if (g_mat) {
+      for (int idx = tid; idx < Bm * S; idx += blockDim.x) {
+        int bm = idx / S, k = idx - bm * S;
+        float gm[7];
+        for (int n = 0; n < 7; ++n) gm[n] = 0.f;
+        int blo = mat_bs ? bm : 0, bhi = mat_bs ? bm + 1 : B;
+        for (int b = blo; b < bhi; ++b) finalize_material<float>(acc + ((size_t)b * S + k) * ACC_STRIDE, light, gm);
+        for (int n = 0; n < 7; ++n) g_mat[(size_t)idx * 7 + n] = gm[n];
+      }
+    }
+    if (g_light) {
+      float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int idx = tid; idx < B * S; idx += blockDim.x) {
+        int b = idx / S, k = idx - b * S;
+        finalize_light_accum<float>(acc + (size_t)idx * ACC_STRIDE, mat + b * mat_bs + 7 * k, gl);
+      }
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const float tot = wave_sum_to_lane63(gl[n]);
+        if (lane == 63) s_red[wave][n] = tot;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float g[6];
+        for (int n = 0; n < 6; ++n) g[n] = s_red[0][n] + s_red[1][n] + s_red[2][n] + s_red[3][n];
+        finalize_light_dir<float>(hdr, g);            // the light is shared by all scenes
+        for (int n = 0; n < 6; ++n) g_light[n] = g[n];
+      }
+    }
+  }
+  __syncthreads();                                   // every read of acc is done
+  for (int idx = tid; idx < B * S * (ACC_STRIDE / 4); idx += blockDim.x)
+    reinterpret_cast<float4*>(acc)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ------------------------------------------------------------------- host --
 thread_local int g_last_hip_error = 0;
 
@@ -2143,7 +2303,9 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
   if (g.acc_repl == 8) RRT_LAUNCH_FINALIZE(8);
   else if (g.acc_repl == 4) RRT_LAUNCH_FINALIZE(4);
   else if (g.acc_repl == 2) RRT_LAUNCH_FINALIZE(2);
-  else RRT_LAUNCH_FINALIZE(1);
+  else
+    hipLaunchKernelGGL(k_finalize_one, dim3(1), dim3(256), 0, st, s->S, s->B, a.acc, a.hdr, s->material,
+                       (long long)s->material_bstride, s->light, (long long)s->w2o_bstride, g_w2o, g_material, g_light);
 #undef RRT_LAUNCH_FINALIZE
   e = hipGetLastError();
   return e == hipSuccess ? RRT_OK : hip_fail(e);
