@@ -134,7 +134,7 @@ int rrt_last_hip_error(void);
 
 /* Bytes of device scratch either render call needs (16-byte aligned base, no
  * initialisation required).  Holds the packed per-(scene,shape) parameters,
- * per-scene headers, the float32 gradient accumulators, the per-tile candidate
+ * per-scene headers, the float32 gradient accumulators (up to four copies), the per-tile candidate
  * masks and tile lists, and the work-queue batches of the last render kernel
  * (about 24 B per 64xP-pixel tile).  Returns 0 on invalid arguments. */
 size_t rrt_workspace_bytes(const rrt_scene* s, const rrt_view* v);
