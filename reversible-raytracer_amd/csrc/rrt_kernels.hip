@@ -608,6 +608,25 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
   }
 }
 
+// k_fwd's image stores: buffer_store_dwordx3 through a per-tile buffer resource -- the tile's first row as the base, the
+// row as a scalar offset, the lane's 12-byte slot as the vector offset: no address arithmetic on the VALU -- WRITTEN THROUGH
+// (sc1).  A plain store leaves its line dirty in the XCD's L2 and the end of the kernel writes back what has piled up
+// there; written through, the lines leave L2 as they come: a kernel of nothing but these stores takes 24.6 instead of 26.2 us
+// (tools/ubench/store_patterns.hip; nt stores 37 us), k_fwd 31.0 instead of 32.0 (three A/B rounds on one box).
+#ifndef RRT_FWD_STORE_AUX
+#define RRT_FWD_STORE_AUX 16          // cache-policy bits of the store: 0 plain, 16 sc1, 17 sc0 sc1, 2 nt
+#endif
+typedef float v3f __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(char* first_row) {
+  // raw buffer (stride 0), no real bound (a tile's stores stay within P rows of its base), gfx9 32-bit float format word
+  return __builtin_amdgcn_make_buffer_rsrc(first_row, 0, 0x7fffffff, 0x27000);
+}
+__device__ __forceinline__ void store_rgb(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned row_off, float r, float g, float b) {
+  const v3f v = {r, g, b};
+  __builtin_amdgcn_raw_buffer_store_b96(v, rs, (int)lane_off, (int)row_off, RRT_FWD_STORE_AUX);
+}
+
+
 // First row of tile t in an image / gradient buffer [B][rows][ncols][3], as a wave-uniform byte pointer.
 __device__ __forceinline__ char* tile_row_ptr(const float* buf, const Tile& t) {
   ckargs ka = kargs_here();
@@ -881,16 +900,14 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
   auto zero_tile = [&](unsigned long long e) {
     int k0; bool multi; long long tile;
     const Tile t = decode_entry(a, e, k0, multi, tile);
-    // (a wave-uniform row address in SGPRs -- one scalar add per row -- plus the lane's 12-byte slot as a 32-bit vector
-    // offset: the saddr form of global_store; as `image + (...) * 3` with the lane folded into a 64-bit vector base, every
-    // row cost two v_mad_u64_u32)
-    char* row = tile_row_ptr(a.image, t);
-    const size_t row_bytes = (size_t)kargs_here()->v.ncols * 12;
+    // (the tile's first row as a buffer resource, the row a scalar offset, the lane's 12-byte slot the vector offset; as
+    // `image + (...) * 3` with the lane folded into a 64-bit vector base, every row cost two v_mad_u64_u32)
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile_row_ptr(a.image, t));
+    const unsigned row_bytes = (unsigned)kargs_here()->v.ncols * 12u;
     if (lane < t.ncols) {
-      const F3 zero = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        if (p < t.nrows) *reinterpret_cast<F3*>(row + p * row_bytes + lane12) = zero;
+        if (p < t.nrows) store_rgb(rs, lane12, p * row_bytes, 0.f, 0.f, 0.f);
       }
     }
   };
@@ -1048,15 +1065,12 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
       asm volatile("" : "+s"(a0), "+s"(b0));
       Tile ts = t;
       ts.a0 = a0; ts.b0 = b0;
-      char* row = tile_row_ptr(a.image, ts);         // (scalar base + 32-bit lane offset, as in zero_tile)
-      const size_t row_bytes = (size_t)kargs_here()->v.ncols * 12;
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile_row_ptr(a.image, ts));      // (as in zero_tile)
+      const unsigned row_bytes = (unsigned)kargs_here()->v.ncols * 12u;
       if (lane < t.ncols) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          if (p < t.nrows) {
-            F3 val = {c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A};
-            *reinterpret_cast<F3*>(row + p * row_bytes + lane12) = val;
-          }
+          if (p < t.nrows) store_rgb(rs, lane12, p * row_bytes, c[p][0] * v.inv_A, c[p][1] * v.inv_A, c[p][2] * v.inv_A);
         }
       }
     };

@@ -9,7 +9,7 @@
 //   mode 0  slab:        workgroup b writes the contiguous 768 KB [b * 768 KB, (b + 1) * 768 KB)          (reference)
 //   mode 1  region:      workgroup = a 256 x 256-pixel region of the image, its units in order
 //   mode 2  interleaved: the image's units in linear order, unit u belongs to workgroup u mod 256 (k_fwd's deal)
-//   mode 3  interleaved with `fma` dependent FMAs per lane between two units (arithmetic under the stores)
+//   mode 4 / 5 / 6  interleaved, one tile per unit, stores with sc1 / sc0 sc1 / nt
 // Prints the time per launch (HIP events over 20 launches) for each.
 #include <hip/hip_runtime.h>
 
@@ -21,6 +21,10 @@ typedef float v3f __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void st3(char* p, v3f v) {
   asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
+// cache-policy variants of the same store (mode 4: sc1, 5: sc0 sc1, 6: nt)
+__device__ __forceinline__ void st3_sc1(char* p, v3f v) { asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st3_sc01(char* p, v3f v) { asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st3_nt(char* p, v3f v) { asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); }
 
 __global__ __launch_bounds__(1024) void k_pattern(float* buf, int mode, int tw, int fma, float* sink) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -35,6 +39,16 @@ __global__ __launch_bounds__(1024) void k_pattern(float* buf, int mode, int tw, 
   float x = (float)lane;
   for (int i = wave; i < per_wg; i += 16) {
     int ux, uy;
+    if (mode >= 4) {            // interleaved tiles (as mode 2, one tile per unit) with a cache policy on the stores
+      const int u = i * 256 + (int)blockIdx.x;
+      char* base = img + ((size_t)(u / 64) * 4 * 4096 + (size_t)(u % 64) * 64) * 12 + lane * 12;
+      for (int p = 0; p < 4; ++p) {
+        if (mode == 4) st3_sc1(base + (size_t)p * 49152, zero);
+        else if (mode == 5) st3_sc01(base + (size_t)p * 49152, zero);
+        else st3_nt(base + (size_t)p * 49152, zero);
+      }
+      continue;
+    }
     if (mode == 1) {
       const int bx = blockIdx.x & 15, by = blockIdx.x >> 4, rx_n = 4 / tw;
       ux = bx * rx_n + i % rx_n; uy = by * 64 + i / rx_n;
@@ -59,7 +73,7 @@ int main() {
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   struct Case { int mode, tw, fma; };
   const Case cases[] = {{0, 1, 0}, {1, 1, 0}, {1, 2, 0}, {1, 4, 0}, {2, 1, 0}, {2, 2, 0}, {2, 4, 0},
-                        {3, 1, 0}, {3, 1, 200}, {3, 1, 400}, {3, 1, 800}, {3, 1, 1600}, {3, 4, 1600}, {0, 1, 0}};
+                        {4, 1, 0}, {5, 1, 0}, {6, 1, 0}, {0, 1, 0}};
   for (int rep = 0; rep < 2; ++rep) {
     for (const Case& c : cases) {
       for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k_pattern, dim3(256), dim3(1024), 0, 0, d_buf, c.mode, c.tw, c.fma, d_sink);
