@@ -808,6 +808,48 @@ def test_weighted_zero_tile_shares(dev, shares, chunk, monkeypatch):
         assert_grad_close(a, b, what, rtol=1e-4)
 
 
+@pytest.mark.parametrize("copies", [1, 2, 8])
+def test_accumulator_copies(dev, copies, monkeypatch):
+    """k_bwd's workgroups add their gradient sums to one of R copies of the accumulator rows (same-line float
+    atomics serialise: DESIGN.md section 5; default R = 4) and k_finalize sums the copies and leaves them zeroed.
+    Any R gives the same gradients -- one scene, and a batch with shared materials (summed over the scenes) -- also
+    for a second backward on the same workspace (the copies must have been re-zeroed)."""
+    import rrt
+    from rrt import synthetic, _native
+    w2o, mat, light, kinds = synthetic.random_spheres(9, seed=6)
+    G = np.random.RandomState(4).randn(384, 512, 3)
+    kw = dict(x_dims=384, y_dims=512, antialias_samples=2, jitter=5)
+
+    def batch():
+        tw = torch.tensor(np.stack([w2o, w2o[::-1].copy(), w2o]), device=dev, requires_grad=True)      # [3, S, 3, 4]
+        tm = torch.tensor(mat, device=dev, requires_grad=True)                                         # shared
+        tl = torch.tensor(light, device=dev, requires_grad=True)
+        g = torch.tensor(np.random.RandomState(5).randn(3, 96, 96, 3).astype(np.float32), device=dev)
+        out = []
+        for _ in range(2):                         # two forward / backward pairs: fresh workspaces, then reused memory
+            for t in (tw, tm, tl):
+                t.grad = None
+            img = rrt.render(tw, tm, tl, kinds, x_dims=96, y_dims=96, antialias_samples=1)
+            (img * g).sum().backward()
+            out.append([t.grad.cpu().double().numpy() for t in (tw, tm, tl)])
+        torch.cuda.synchronize()
+        return out
+    ref, ref_b = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw), batch()
+    monkeypatch.setenv("RRT_TUNE_REPL", str(copies))
+    _native.lib().rrt_debug_reload_tuning()
+    try:
+        got, got_b = hip_render(dev, w2o, mat, light, kinds, grad=G, **kw), batch()
+    finally:
+        monkeypatch.delenv("RRT_TUNE_REPL")
+        _native.lib().rrt_debug_reload_tuning()
+    assert np.array_equal(got[0], ref[0])
+    for a, b, what in zip(got[1:], ref[1:], ("g_w2o", "g_material", "g_light")):
+        assert_grad_close(a, b, what, rtol=1e-4)
+    for rnd in range(2):
+        for a, b, what in zip(got_b[rnd], ref_b[0], ("g_w2o", "g_material", "g_light")):
+            assert_grad_close(a, b, "batch round %d %s" % (rnd, what), rtol=1e-4)
+
+
 def test_backward_with_and_without_saved_queues(dev, monkeypatch):
     """a backward on the forward's setup reads the queue batches the forward
     dealt; RRT_TUNE_NOSAVED makes it deal them again -- same gradients"""
