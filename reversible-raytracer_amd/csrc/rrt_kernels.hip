@@ -142,6 +142,7 @@ struct KArgs {
   int chunk;                      // list segments per queue batch: at most one per thread, and few enough that a
                                   // workgroup's share of their tiles fits its queues (Q_CAP)
   int zw_even, zw_odd;            // k_fwd: shares of the zero-filled tiles, workgroups with even : odd blockIdx (XcdDeal)
+  int ztail;                      // k_fwd: per cent of a workgroup's zero-filled tiles kept back for its waves' idle ends
   const float* jitter;            // explicit sampleDist or nullptr
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
@@ -961,7 +962,10 @@ __global__ __launch_bounds__(BLOCK, RRT_FWD_WAVES_PER_SIMD) void k_fwd(KArgs a) 
                              a.wgq + slot * Q_CAP, a.wgq_cnt + slot, (unsigned)a.zw_even, (unsigned)a.zw_odd);
       cnt_e = qs.cnt_e;
     }
-    const unsigned per = cnt ? (cnt_e + cnt - 1) / cnt : 0;
+    // zero-filled tiles handed out with every rendered tile.  Not all of them: a share (a.ztail per cent) stays behind for
+    // the waves that run out of tiles to render -- a zero-filled tile is 0.1 us of work, the ideal filler for the 2-3 us
+    // between the first and the last wave of a workgroup leaving its render loop
+    const unsigned per = cnt ? (cnt_e * (100u - (unsigned)a.ztail) / 100u + cnt - 1) / cnt : 0;
     RRT_STAMP_FWD(1, ~0ull);
     unsigned long long e_cur;
     bool more_zero = cnt_e > 0;
@@ -1978,6 +1982,8 @@ struct Tune {
   int P = 0;              // RRT_TUNE_P=1|2|4: rows per wave tile
   int fwd_wgs = 0, bwd_wgs = 0, chunk = 0;
   int repl = 4;                  // RRT_TUNE_REPL=1|2|4|8: copies of the gradient-accumulator rows (KArgs::acc_repl)
+  int ztail = 20;                // RRT_TUNE_ZTAIL=0..90: per cent of the zero-filled tiles kept for the end of the render loop
+                                 // (sweep 0 / 15 / 30 / 50 / 70: 71.9 / 71.5 / 71.6 / 72.3 / 73.0 us per step, three rounds)
   int zw_even = 6, zw_odd = 5;   // RRT_TUNE_ZW=even:odd  shares of k_fwd's zero-filled tiles by blockIdx parity (XcdDeal;
                                  // sweep 1:1 ... 4:3, profiles/r03_xcd_store_asymmetry.txt: flat between 7:6 and 5:4)
   bool no_lds = false, no_saved = false;
@@ -1991,6 +1997,7 @@ void read_tune(Tune& x) {
   x.fwd_wgs = num("RRT_TUNE_FWD_WGS");
   x.bwd_wgs = num("RRT_TUNE_BWD_WGS");
   x.chunk = num("RRT_TUNE_CHUNK");
+  if (getenv("RRT_TUNE_ZTAIL")) { const int z = num("RRT_TUNE_ZTAIL"); x.ztail = z < 0 ? 0 : (z > 90 ? 90 : z); }
   if (getenv("RRT_TUNE_REPL")) { const int r = num("RRT_TUNE_REPL"); x.repl = r >= 8 ? 8 : (r >= 4 ? 4 : (r >= 2 ? 2 : 1)); }
   if (const char* zw = getenv("RRT_TUNE_ZW")) {
     int we = 0, wo = 0;
@@ -2137,6 +2144,7 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.chunk = g.chunk;
   // weighted shares only where a favoured workgroup's share surely fits its zero queue (average share <= Q_CAP / 2)
   const bool weigh = (long long)g.n_bins * SEG * 2 <= (long long)Q_CAP * g.blocks_fwd && !(g.blocks_fwd & 1u);
+  a.ztail = tune().ztail;
   a.zw_even = weigh ? tune().zw_even : 1;
   a.zw_odd = weigh ? tune().zw_odd : 1;
   a.n_waves = 0;
