@@ -12,9 +12,14 @@ floor of the same formulas measured on the CPU harness (test_device_math.py):
     float32 rounding at grazing rays, and the reference itself rounds its rays to
     float32 -- measured at the same point by the oracle run in float32:
     max|d| <= 4 x (float32 oracle's error), and that only up to GRAD_RTOL * max|g|
-    (5e-3; 2e-2 for the thin white-noise band) unless a hit/miss flip is actually
-    present (a pixel of the GPU image off by more than IMG_TOL, or a ray whose
-    winner differs between the float32 and the float64 oracle, ``oracle.hit_ids``).
+    (5e-3; 2e-2 for the thin white-noise band) unless a ray is present whose
+    float32 arithmetic is undecidable: a hit/miss flip (a pixel of the GPU image
+    off by more than IMG_TOL, or a ray whose winner differs between the float32
+    and the float64 oracle, ``oracle.hit_ids``), or a ray so close to grazing that
+    the float32 ORACLE ITSELF misses that cap on the tensor (round-3 soak of 200
+    random scenes: eight such cases, no flip, float32 oracle off by 1.3e-2 ...
+    1.7e-1 of max|g|, the GPU by 5e-3 ... 1.6e-2 -- its discriminant is the better
+    conditioned one -- and the product's own math in float64 within 5e-6).
     With such an undecidable ray present even that bound can fail -- the ray's
     weight 1 / sqrt(discriminant) is unbounded and one of them can outweigh the
     rest of the image (seen: 8.7 x max|g| at 33 x 33 pixels) -- and then the
@@ -50,7 +55,9 @@ MAX_FLIP_FRAC = 5e-4
 GRAD_TIGHT = 1e-3
 GRAD_RTOL = 5e-3
 ENTRY_RTOL = 5e-3
-ENTRY_FLOOR = 2e-5
+# (float32 noise on small entries, round-3 soak: 3e-5 and 8.2e-5 of max|g| on entries 1.5e-3 / 3e-4 of the tensor's scale (seeds
+# 159, 259); the product's math run in float32 on the CPU shows the same 8e-5, in float64 3e-11)
+ENTRY_FLOOR = 1e-4
 GRAZING_MARGIN = 1e-4
 
 _REPORT = []
@@ -166,14 +173,17 @@ def assert_grads_vs_oracle(got, ref, f32, image_flips, count_flips, loose=None):
             continue
         scale = max(np.abs(b).max(), 1e-20)
         err = np.abs(a - b)
-        tol, fallback = GRAD_TIGHT * scale, False
+        tol, fallback, undecidable = GRAD_TIGHT * scale, False, False
         if err.max() > tol:
-            fl = 4.0 * np.abs(np.asarray(floor()[idx]) - b).max()
+            fl_raw = np.abs(np.asarray(floor()[idx]) - b).max()
+            fl = 4.0 * fl_raw
             cap = (loose or GRAD_RTOL) * scale
-            tol, fallback = max(tol, fl if flips() > 0 else min(fl, cap)), True
+            # undecidable in float32: a hit/miss flip, or the float32 oracle itself beyond the cap on this tensor
+            undecidable = flips() > 0 or fl_raw > cap
+            tol, fallback = max(tol, fl if undecidable else min(fl, cap)), True
             used_fallback = True
         _note(what, float(err.max() / scale), cache.get("flips", image_flips), fallback)
-        if fallback and flips() > 0 and err.max() > tol:
+        if fallback and undecidable and err.max() > tol:
             # A ray whose hit / miss is undecidable in float32 is present, and its weight 1 / sqrt(discriminant) has no
             # bound: one such ray can outweigh the rest of the image (seen: 8.7 x max|g|), in the GPU's float32, in the
             # float32 oracle's, or in both, differently.  No bound on the full sum is meaningful then -- the caller's
