@@ -24,9 +24,12 @@
 //               by one ds_read_b32 + v_readlane (scalar loads through the
 //               constant address space when the scene is too big); rays are
 //               generated in registers; winners are shaded shape by shape; each
-//               lane stores its RGB triple with one global_store_dwordx3 (a wave
-//               row is 768 contiguous bytes).  The dealt queue batch is kept in
-//               the workspace for the backward.
+//               lane stores its RGB triple with one buffer_store_dwordx3 (a wave
+//               row is 768 contiguous bytes), written through (sc1): no dirty
+//               lines are left for the kernel's end to write back.  The tiles
+//               that are only zero-filled are dealt 6:5 to workgroups of even:odd
+//               blockIdx (the odd XCDs of an MI355X store ~15 % slower).  The
+//               dealt queue batch is kept in the workspace for the backward.
 //   k_bwd<P>    persistent, one 1024-thread workgroup per CU with the same LDS
 //               work queue (read back from the forward's batch when there was
 //               one); tiles without candidates never touch the upstream
@@ -37,9 +40,10 @@
 //               accumulators; these are summed across the wave by a transposing
 //               butterfly (v_permlane32_swap, v_permlane16_swap, DPP), added to
 //               workgroup-level LDS accumulators, and each workgroup adds a
-//               touched shape row to HBM once (global_atomic_add_f32).
-//   k_finalize  chain the accumulator rows back to w2o / material / light and
-//               re-zero them.
+//               touched shape row to HBM once (global_atomic_add_f32) -- to one of
+//               four copies of the rows: same-line float atomics serialise.
+//   k_finalize  sum the copies, chain the accumulator rows back to w2o /
+//               material / light and re-zero them.
 //
 // No MFMA: the path is per-ray quadratic solves, not a contraction.
 // Environment variables RRT_TUNE_* are tuning knobs for experiments and tests (tile
