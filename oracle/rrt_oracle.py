@@ -450,11 +450,17 @@ def hit_ids(w2o, kinds=None, *, x_dims, y_dims, antialias_samples=1,
     miss.  Test helper: lets parity checks separate pixels whose winner differs
     between float32 and float64 (silhouettes) from genuine errors.
 
-    ``with_margin=True`` also returns, per ray, min over the spheres of
-    |discriminant| / (p.v)^2 (shape.py:78-83's quantity, relative): how close the
-    ray is to grazing a sphere.  d colour / d parameter carries 1 / sqrt(discriminant)
-    (shape.py:109-126's sqrt), so rays with a tiny margin have unbounded weight in a
-    gradient and a float32 evaluation of them is ill-conditioned whoever does it."""
+    ``with_margin=True`` also returns, per ray, how close the ray is to one of the
+    DISCRETE decisions of the render, as a relative quantity:
+      * min over the spheres of |discriminant| / (p.v)^2 (shape.py:78-83's quantity):
+        how close the ray is to grazing a sphere.  d colour / d parameter carries
+        1 / sqrt(discriminant) (shape.py:109-126's sqrt), so rays with a tiny margin
+        have unbounded weight in a gradient and a float32 evaluation of them is
+        ill-conditioned whoever does it;
+      * min over the squares of the distance of the ray's plane point to an edge
+        line, | |x| - 0.5 | / 0.5 and the same in y (shape.py:33-38's strict tests);
+      * the relative gap between the two nearest hits (scene.py:46's strict '<').
+    A float32 evaluation can take the other branch on such a ray."""
     w2o = torch.as_tensor(w2o).to(dtype)
     S = w2o.shape[0]
     if kinds is None:
@@ -491,12 +497,26 @@ def hit_ids(w2o, kinds=None, *, x_dims, y_dims, antialias_samples=1,
                     ids = torch.full(dists.shape, -1, dtype=torch.int64)
                     min_dists = torch.full(dists.shape, INF, dtype=dtype)
                     margin = torch.full(dists.shape, INF, dtype=dtype)
+                if with_margin:
+                    # the gap to the nearest hit so far (depth ties), before this shape is merged in
+                    both = torch.isfinite(dists) & torch.isfinite(min_dists)
+                    gap = (dists - min_dists).abs() / torch.maximum(dists.abs(), min_dists.abs()).clamp_min(1e-300)
+                    margin = torch.where(both, torch.minimum(margin, gap), margin)
                 sel = dists < min_dists
                 ids = torch.where(sel, torch.full_like(ids, k), ids)
                 min_dists = torch.where(sel, dists, min_dists)
                 if with_margin and kinds[k] == SPHERE:
                     pdotv = torch.tensordot(r_k, o_k, dims=1)
                     margin = torch.minimum(margin, sphere_hit(r_k, o_k).abs() / (pdotv * pdotv).clamp_min(1e-300))
+                elif with_margin:
+                    rz = r_k[..., 2]
+                    ok = rz != 0
+                    tt = -o_k[2] / torch.where(ok, rz, torch.ones_like(rz))
+                    px, py = o_k[0] + tt * r_k[..., 0], o_k[1] + tt * r_k[..., 1]
+                    edge = torch.minimum((px.abs() - 0.5).abs(), (py.abs() - 0.5).abs()) / 0.5
+                    # (only rays that reach the plane in front of them anywhere near the square)
+                    near_sq = ok & (tt > 0) & (px.abs() < 0.75) & (py.abs() < 0.75)
+                    margin = torch.where(near_sq, torch.minimum(margin, edge), margin)
             out.append(ids)
             margins.append(margin)
     if with_margin:
