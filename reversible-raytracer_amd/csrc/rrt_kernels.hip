@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256) void k_prep(KArgs a, PrepArgs pa) {
     pixel_to_ray(a.v, ra1 + a.v.row0, rb1, i1, j1);
     region = tile_cone<float>(a.v, i0, i1, j0, j1);
   }
-  if (owner && tid == 0) pack_header<float, float>(cam, pa.light, pa.hdr + (size_t)b * HDR_STRIDE);
+  // (the scene's header: by a thread of the LAST wave -- the first waves pack shapes, and the owner block, one per CU like
+  // every other, is the one the kernel waits for)
+  if (owner && tid == 192) pack_header<float, float>(cam, pa.light, pa.hdr + (size_t)b * HDR_STRIDE);
   {
     // the scene's gradient-accumulator rows, every copy: a slice per block of the scene (k_finalize leaves them zeroed
     // too; this covers a fresh workspace)
