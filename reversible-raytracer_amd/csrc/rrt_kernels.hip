@@ -42,13 +42,16 @@
 //               workgroup-level LDS accumulators, and each workgroup adds a
 //               touched shape row to HBM once (global_atomic_add_f32) -- to one of
 //               four copies of the rows: same-line float atomics serialise.
+//               Small images with several samples per pixel (fewer than 4 tiles
+//               per wave): every queue entry is handed out 2 or 4 times and the
+//               waves share the tile's samples (k_bwd<..., SP = 1>).
 //   k_finalize  sum the copies, chain the accumulator rows back to w2o /
 //               material / light and re-zero them.
 //
 // No MFMA: the path is per-ray quadratic solves, not a contraction.
 // Environment variables RRT_TUNE_* are tuning knobs for experiments and tests (tile
 // rows, persistent grid sizes, LDS staging on/off, queue batch size, saved queues
-// on/off); defaults are what was measured best.
+// on/off, sample split); defaults are what was measured best.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -151,6 +154,8 @@ struct KArgs {
   float* image;                   // fwd: [B][rows][ncols][3]
   const float* grad;              // bwd: same layout
   float* acc;                     // bwd: [acc_repl][B][S][ACC_STRIDE]
+  int split_log2;                 // k_bwd<SP = 1>: a queue entry is pulled 1 << split_log2 times, each wave taking an equal part of
+                                  // the tile's antialiasing samples (small images: a wave's one or two tiles are the critical path)
   int acc_repl;                   // copies of the accumulator rows: workgroup b of k_bwd adds to copy b mod acc_repl and
                                   // k_finalize sums the copies.  Same-line float atomics serialise at ~13 ns each: with one
                                   // copy all 256 workgroups queue on every shape's line -- 3.5 us at the end of k_bwd
@@ -864,6 +869,22 @@ __device__ __forceinline__ bool queue_pop(WgQueue& q, unsigned cnt, int lane, un
   return true;
 }
 
+// k_bwd: the same, every entry handed out 1 << split_log2 times (consecutively: the waves that share a tile run together and
+// find its gradient rows in the L2); `part` says which share of the samples the caller got.  SP = 0: queue_pop.
+template <int SP>
+__device__ __forceinline__ bool queue_pop_part(WgQueue& q, unsigned cnt, int lane, unsigned long long& e, int& part) {
+  if (!SP) { part = 0; return queue_pop(q, cnt, lane, e); }
+  const int sl = kargs_here()->split_log2;
+  unsigned i = 0;
+  if (lane == 0) i = atomicAdd(&q.cursor, 1u);
+  i = __builtin_amdgcn_readfirstlane(i);
+  if (i >= (cnt << sl)) return false;
+  e = q.ent[i >> sl];
+  e = lane_bcast64(e, 0);
+  part = (int)(i & ((1u << sl) - 1u));
+  return true;
+}
+
 #ifndef RRT_BWD_WAVES_PER_SIMD
 #define RRT_BWD_WAVES_PER_SIMD 1
 #endif
@@ -1207,6 +1228,7 @@ __device__ __forceinline__ void prefetch_grad_rows(const KArgs& a, const Tile& t
 struct BwdWave {
   unsigned long long e_cur, e_nxt;   // current entry, next entry (its gradient rows are in flight)
   bool has_cur;
+  int part_cur, part_nxt;            // (SP) which share of the tile's samples this wave works on
   int buf;                           // which half of the wave's gradient double buffer holds the current tile's rows
   int b_cur;                         // scene whose constants `sc` holds
   SceneP sc;
@@ -1301,7 +1323,7 @@ __device__ __attribute__((noinline)) GenericSums bwd_generic_shape(int tb, int t
 // samples run INSIDE the accumulation, so the tile pays one butterfly.  A workgroup's queue is
 // ordered by cost class (3+ candidates, 2, 1), so a wave runs its MULTI tiles in one loop and its
 // single-candidate tiles in a second, leaner one (fewer live scalars: the general loop spills SGPRs).
-template <int P, int SHADER, int SPEC, int JC, int TR, bool MULTI, int SH>
+template <int P, int SHADER, int SPEC, int JC, int TR, bool MULTI, int SH, int SP>
 __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_q, unsigned cnt, const float* s_scene,
                                          float* s_acc, float* s_up_wave, int (*s_best_wave)[64], int lane) {
   const ViewK& v = a.v;
@@ -1329,7 +1351,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
     w.held = false;
   }
   // (3) pull the next tile and request its gradient rows
-  const bool has_nxt = queue_pop(s_q, cnt, lane, w.e_nxt);
+  const bool has_nxt = queue_pop_part<SP>(s_q, cnt, lane, w.e_nxt, w.part_nxt);
   if (has_nxt) {
     int k1; bool m1; long long tl1;
     const Tile tn = decode_entry(a, w.e_nxt, k1, m1, tl1);
@@ -1339,9 +1361,12 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
   cuptr mk = as_const(kargs_here()->mask) + tile * kargs_here()->nwords;
   RRT_STAMP(2);
 
+  // (SP) this wave's share of the samples
+  const int smp_lo = SP ? (w.part_cur * v.A) >> kargs_here()->split_log2 : 0;
+  const int smp_hi = SP ? ((w.part_cur + 1) * v.A) >> kargs_here()->split_log2 : v.A;
 #pragma unroll 1
-  for (int s0 = 0; s0 < (MULTI ? v.A : 1); ++s0) {
-    const int s_lo = MULTI ? s0 : 0, s_hi = MULTI ? s0 + 1 : v.A;
+  for (int s0 = MULTI ? smp_lo : 0; s0 < (MULTI ? smp_hi : 1); ++s0) {
+    const int s_lo = MULTI ? s0 : smp_lo, s_hi = MULTI ? s0 + 1 : smp_hi;
     if (MULTI) {
       const int s = s0;
       // several candidates: settle every ray's winner first
@@ -1524,6 +1549,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
   RRT_STAMP(8);
   RRT_STAMP_RT(15);
   w.e_cur = w.e_nxt;
+  if (SP) w.part_cur = w.part_nxt;
   w.has_cur = has_nxt;
   w.buf ^= 1;
 }
@@ -1532,7 +1558,7 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
 // the upstream gradient), pulled from the workgroup's LDS queue.  The next
 // tile's gradient rows are requested before the current tile is processed, so
 // HBM latency hides behind the adjoint.
-template <int P, int SHADER, int SPEC, int JC, int TR, int SH>
+template <int P, int SHADER, int SPEC, int JC, int TR, int SH, int SP = 0>
 __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) {
   __shared__ float s_scene[LDS_RECS * PS_STRIDE];
   __shared__ WgQueue s_q;
@@ -1568,7 +1594,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     for (int i = threadIdx.x; i < a.B * a.S * ACC_STRIDE; i += blockDim.x) s_acc[i] = 0.f;
   stage_scene(a, s_scene);          // ends with the workgroup barrier
   BwdWave w;
-  w.e_cur = w.e_nxt = 0; w.has_cur = false; w.buf = 0; w.b_cur = -1;
+  w.e_cur = w.e_nxt = 0; w.has_cur = false; w.buf = 0; w.b_cur = -1; w.part_cur = w.part_nxt = 0;
   w.sc = {{0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, 1.f};
   w.held = false; w.held_k = w.held_b = 0; w.held_val = 0.f;
   float* const s_up_wave = &s_up[wave][0][0][0];
@@ -1622,7 +1648,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
                                 a.wgq + slot * Q_CAP, a.wgq_cnt + slot);
       }
     }
-    w.has_cur = queue_pop(s_q, cnt, lane, w.e_cur);
+    w.has_cur = queue_pop_part<SP>(s_q, cnt, lane, w.e_cur, w.part_cur);
     w.buf = 0;
     if (w.has_cur) {
       int k0; bool multi; long long tile;
@@ -1631,11 +1657,11 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
     }
     // the queue is ordered by cost class: first the tiles with several candidates, then the others
     while (w.has_cur && entry_is_multi(w.e_cur))
-      bwd_tile<P, SHADER, SPEC, JC, TR, true, SH>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
+      bwd_tile<P, SHADER, SPEC, JC, TR, true, SH, SP>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
     // (queue_fill stages a workgroup's share in list order -- class 0, 1, 2 -- and the saved batches keep
     // that order: no entry with several candidates follows one with a single candidate)
     while (w.has_cur)
-      bwd_tile<P, SHADER, SPEC, JC, TR, false, SH>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
+      bwd_tile<P, SHADER, SPEC, JC, TR, false, SH, SP>(a, w, s_q, cnt, s_scene, s_acc, s_up_wave, s_best_wave, lane);
   }
   if (w.held && lane < ACC_USED)
     __hip_atomic_fetch_add(acc_copy(a) + ((size_t)w.held_b * a.S + w.held_k) * ACC_STRIDE + lane, w.held_val, __ATOMIC_RELAXED,
@@ -1999,6 +2025,7 @@ struct Tune {
                                  // (sweep 0 / 15 / 30 / 50 / 70: 71.9 / 71.5 / 71.6 / 72.3 / 73.0 us per step, three rounds)
   int zw_even = 6, zw_odd = 5;   // RRT_TUNE_ZW=even:odd  shares of k_fwd's zero-filled tiles by blockIdx parity (XcdDeal;
                                  // sweep 1:1 ... 4:3, profiles/r03_xcd_store_asymmetry.txt: flat between 7:6 and 5:4)
+  int split = -1;                // RRT_TUNE_SPLIT=0|2|4: waves that share a tile's samples in k_bwd (KArgs::split_log2); -1 = by size
   bool no_lds = false, no_saved = false;
 };
 Tune g_tune;
@@ -2016,6 +2043,8 @@ void read_tune(Tune& x) {
     int we = 0, wo = 0;
     if (sscanf(zw, "%d:%d", &we, &wo) == 2 && wo >= 1 && we >= wo && we <= 64) { x.zw_even = we; x.zw_odd = wo; }
   }
+  x.split = -1;
+  if (getenv("RRT_TUNE_SPLIT")) { const int sp = num("RRT_TUNE_SPLIT"); x.split = sp >= 4 ? 4 : (sp >= 2 ? 2 : 0); }
   x.no_lds = getenv("RRT_TUNE_NOLDS") != nullptr;
   x.no_saved = getenv("RRT_TUNE_NOSAVED") != nullptr;
 }
@@ -2144,6 +2173,7 @@ KArgs make_args(const rrt_scene* s, const rrt_view* v, void* workspace, const Ge
   a.hdr = (const float*)(base + g.hdr_off);
   a.acc = (float*)(base + g.acc_off);
   a.acc_repl = g.acc_repl;
+  a.split_log2 = 0;
   a.mask = (const unsigned long long*)(base + g.mask_off);
   a.heavy = (const unsigned long long*)(base + g.heavy_off);
   a.empty = (const unsigned long long*)(base + g.empty_off);
@@ -2211,6 +2241,11 @@ void launch_bwd_jt(const KArgs& a, unsigned blocks, int shader, int spec, hipStr
   if (shader == SHADER_DEPTH) hipLaunchKernelGGL((k_bwd<P, SHADER_DEPTH, 0, 0, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
   else if (sh && spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1, 0, TR, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
   else if (sh) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0, 0, TR, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  else if (P <= 2 && a.split_log2) {
+    // small images with several samples per pixel: the samples of a tile are shared out between waves
+    if (spec) hipLaunchKernelGGL((k_bwd<P <= 2 ? P : 1, SHADER_PHONG, 1, JC, TR, 0, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_bwd<P <= 2 ? P : 1, SHADER_PHONG, 0, JC, TR, 0, 1>), dim3(blocks), dim3(BLOCK), 0, st, a);
+  }
   else if (spec) hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 1, JC, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
   else hipLaunchKernelGGL((k_bwd<P, SHADER_PHONG, 0, JC, TR, 0>), dim3(blocks), dim3(BLOCK), 0, st, a);
 }
@@ -2325,6 +2360,13 @@ int rrt_render_bwd(const rrt_scene* s, const rrt_view* v, const float* grad_imag
     a.n_waves = (int)blocks * WAVES;
     // the kernel that ran on this setup before (forward or backward) left its queue batches behind
     a.use_saved = ((v->flags & RRT_FLAG_REUSE_SETUP) && g.blocks_fwd == g.blocks_bwd && g.lds_mode != 2 && !tune().no_saved) ? 1 : 0;
+    // Tiles of 1 or 2 rows mean fewer than 4 tiles per wave (geometry_of): with several samples per pixel a wave's serial
+    // walk through the samples of its tiles is then the kernel's critical path, and the samples are shared out
+    {
+      int parts = tune().split >= 0 ? tune().split : (a.v.A >= 4 ? 4 : 2);
+      if (parts > a.v.A) parts = a.v.A >= 2 ? 2 : 0;
+      a.split_log2 = (g.P <= 2 && parts >= 2) ? (parts == 4 ? 2 : 1) : 0;
+    }
     if (g.P == 4) launch_bwd<4>(a, blocks, a.v.shader, a.v.specular, st);
     else if (g.P == 2) launch_bwd<2>(a, blocks, a.v.shader, a.v.specular, st);
     else launch_bwd<1>(a, blocks, a.v.shader, a.v.specular, st);

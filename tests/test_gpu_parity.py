@@ -874,6 +874,57 @@ def test_accumulator_copies(dev, copies, monkeypatch):
             assert_grad_close(a, b, "batch round %d %s" % (rnd, what), rtol=1e-4)
 
 
+@pytest.mark.parametrize("samples,parts", [(4, 0), (4, 2), (3, 2), (3, 4), (2, 4), (5, 4)])
+def test_sample_split(dev, samples, parts, monkeypatch):
+    """on small images (tiles of 1 or 2 rows) k_bwd hands every queue entry out 2 or 4 times and each wave takes a share
+    of the tile's antialiasing samples (KArgs::split_log2; default 4 shares from 4 samples on, else 2).  Any split --
+    none, more shares than samples, samples that do not divide -- gives the same gradients: spheres + Square with hash
+    jitter (multi- and single-candidate tiles, the generic adjoint), several queue batches, and a batch of small scenes
+    whose workgroups take whole list segments"""
+    import rrt
+    from rrt import synthetic, _native
+    w2o, mat, light, kinds = synthetic.match_mirror(True)
+    G = np.random.RandomState(4).randn(200, 320, 3)
+    kw = dict(x_dims=200, y_dims=320, antialias_samples=samples, jitter=9)
+    ow, om, ol, kk = synthetic.orbit_scene()
+
+    def batch():
+        B = 160                                   # B * S > 128 records: lds_scene = 2
+        ang = np.linspace(0.0, 2 * np.pi, B, endpoint=False)
+        tw = torch.tensor(np.stack([synthetic.orbit_scene((9 * np.cos(t), 9 * np.sin(t), 32.0))[0] for t in ang]),
+                          device=dev, requires_grad=True)
+        tm = torch.tensor(om, device=dev, requires_grad=True)
+        tl = torch.tensor(ol, device=dev, requires_grad=True)
+        g = torch.tensor(np.random.RandomState(5).randn(B, 32, 32, 3).astype(np.float32), device=dev)
+        cams = np.stack([synthetic.orbit_camera(2.5 if b % 2 == 0 else -2.5) for b in range(B)])
+        img = rrt.render(tw, tm, tl, kk, torch.tensor(cams, device=dev), x_dims=32, y_dims=32, antialias_samples=samples,
+                         specular=False, jitter=4)
+        (img * g).sum().backward()
+        torch.cuda.synchronize()
+        return [t.grad.cpu().double().numpy() for t in (tw, tm, tl)]
+
+    def run():
+        return hip_render(dev, w2o, mat, light, kinds, grad=G, **kw), batch()
+    monkeypatch.setenv("RRT_TUNE_SPLIT", "0")
+    _native.lib().rrt_debug_reload_tuning()
+    try:
+        ref, ref_b = run()
+        monkeypatch.setenv("RRT_TUNE_SPLIT", str(parts))
+        if parts == 2:
+            monkeypatch.setenv("RRT_TUNE_CHUNK", "3")
+        _native.lib().rrt_debug_reload_tuning()
+        got, got_b = run()
+    finally:
+        monkeypatch.delenv("RRT_TUNE_SPLIT")
+        monkeypatch.delenv("RRT_TUNE_CHUNK", raising=False)
+        _native.lib().rrt_debug_reload_tuning()
+    assert np.array_equal(got[0], ref[0])
+    for a, b, what in zip(got[1:], ref[1:], ("g_w2o", "g_material", "g_light")):
+        assert_grad_close(a, b, what, rtol=1e-4)
+    for a, b, what in zip(got_b, ref_b, ("g_w2o", "g_material", "g_light")):
+        assert_grad_close(a, b, "batch " + what, rtol=1e-4)
+
+
 def test_backward_with_and_without_saved_queues(dev, monkeypatch):
     """a backward on the forward's setup reads the queue batches the forward
     dealt; RRT_TUNE_NOSAVED makes it deal them again -- same gradients"""
