@@ -1586,7 +1586,9 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
   unsigned long long saved_ent = 0;
   if (a.use_saved) {
     saved_cnt = as_const_u32(a.wgq_cnt)[blockIdx.x];
-    saved_ent = threadIdx.x < saved_cnt ? a.wgq[(size_t)blockIdx.x * Q_CAP + threadIdx.x] : 0ull;
+    // (the whole slot is allocated: read without waiting for the count -- one memory round trip less at the kernel's
+    // start, k_bwd -0.3 us; entries beyond the count are never used)
+    saved_ent = a.wgq[(size_t)blockIdx.x * Q_CAP + threadIdx.x];
   } else if (threadIdx.x < min(chunk, (unsigned)a.n_bins)) {
     cw = reinterpret_cast<const uint2*>(a.blk_counts)[threadIdx.x];
   }
@@ -1632,7 +1634,7 @@ __global__ __launch_bounds__(BLOCK, RRT_BWD_WAVES_PER_SIMD) void k_bwd(KArgs a) 
         __syncthreads();                     // previous batch fully consumed
         if (a.use_saved) {
           saved_cnt = as_const_u32(a.wgq_cnt)[slot];
-          saved_ent = threadIdx.x < saved_cnt ? a.wgq[slot * Q_CAP + threadIdx.x] : 0ull;
+          saved_ent = a.wgq[slot * Q_CAP + threadIdx.x];
         } else {
           cw = threadIdx.x < nb ? reinterpret_cast<const uint2*>(a.blk_counts)[bin0 + threadIdx.x] : make_uint2(0u, 0u);
         }
