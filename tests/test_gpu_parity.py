@@ -60,7 +60,9 @@ GRAD_RTOL = 5e-3
 ENTRY_RTOL = 5e-3
 # (float32 noise on small entries, round-3 soak: 3e-5 and 8.2e-5 of max|g| on entries 1.5e-3 / 3e-4 of the tensor's scale (seeds
 # 159, 259); the product's math run in float32 on the CPU shows the same 8e-5, in float64 3e-11)
-ENTRY_FLOOR = 1e-4
+# a last soak of 500 more renders (seeds 600..849): one entry at 1.03e-4 (seed 729, an entry of 5e-3 of the scale; the product's
+# math on the CPU: 1.09e-4 in float32, 7e-12 in float64) -- the floor is 2e-4
+ENTRY_FLOOR = 2e-4
 GRAZING_MARGIN = 1e-4
 
 _REPORT = []
