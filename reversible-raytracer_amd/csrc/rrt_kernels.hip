@@ -1338,6 +1338,37 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
   }
   const SceneP& sc = w.sc;
   const bool col_ok = lane < t.ncols;
+  const LaneRay lr = lane_ray<TR>(a, t, lane);
+  cuptr mk = as_const(kargs_here()->mask) + tile * kargs_here()->nwords;
+  // (SP) this wave's share of the samples
+  const int smp_lo = SP ? (w.part_cur * v.A) >> kargs_here()->split_log2 : 0;
+  const int smp_hi = SP ? ((w.part_cur + 1) * v.A) >> kargs_here()->split_log2 : v.A;
+  // several candidates: every ray's winner for one sample
+  auto settle = [&](int s) {
+    float d[P][3], tmin[P];
+    int best[P];
+    gen_rays<P, JC, TR>(a, t, lr, s, d);
+#pragma unroll
+    for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
+    for (int wd = 0; wd < a.nwords; ++wd) {
+      unsigned long long m = mk[wd];
+      while (m) {
+        int k = wd * 64 + __builtin_ctzll(m);
+        m &= m - 1;
+        ShapeP q;
+        shape_head(shape_word(a, s_scene, t.b, k, lane), q);
+        float Av[9], ov[3];
+        load_shape_vgpr(a, s_scene, t.b, k, Av, ov);
+        trace_shape_p<P, false>(q.kind, Av, ov, k, d, best, tmin, nullptr);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) s_best_wave[p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
+  };
+  // the first sample's winners need no gradient: settled BEFORE the wait for the rows.  (Every wave's first tile waits for
+  // its rows together with the 4095 other waves of the chip -- a 12.6-MB burst, >= 2.5 us -- and the queue starts with the
+  // multi-candidate tiles: k_bwd 31.1 -> 30.1 us)
+  if (MULTI) settle(smp_lo);
   // (1) this tile's gradient rows, requested one tile ago, have landed in the wave's buffer once its
   // vector-memory counter is at zero (nothing younger is outstanding at this point)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1357,39 +1388,12 @@ __device__ __forceinline__ void bwd_tile(const KArgs& a, BwdWave& w, WgQueue& s_
     const Tile tn = decode_entry(a, w.e_nxt, k1, m1, tl1);
     prefetch_grad_rows<P>(a, tn, lane, s_up_wave + (w.buf ^ 1) * (P * UP_ROW));
   }
-  const LaneRay lr = lane_ray<TR>(a, t, lane);
-  cuptr mk = as_const(kargs_here()->mask) + tile * kargs_here()->nwords;
   RRT_STAMP(2);
 
-  // (SP) this wave's share of the samples
-  const int smp_lo = SP ? (w.part_cur * v.A) >> kargs_here()->split_log2 : 0;
-  const int smp_hi = SP ? ((w.part_cur + 1) * v.A) >> kargs_here()->split_log2 : v.A;
 #pragma unroll 1
   for (int s0 = MULTI ? smp_lo : 0; s0 < (MULTI ? smp_hi : 1); ++s0) {
     const int s_lo = MULTI ? s0 : smp_lo, s_hi = MULTI ? s0 + 1 : smp_hi;
-    if (MULTI) {
-      const int s = s0;
-      // several candidates: settle every ray's winner first
-      float d[P][3], tmin[P];
-      int best[P];
-      gen_rays<P, JC, TR>(a, t, lr, s, d);
-#pragma unroll
-      for (int p = 0; p < P; ++p) { best[p] = -1; tmin[p] = INFINITY; }
-      for (int wd = 0; wd < a.nwords; ++wd) {
-        unsigned long long m = mk[wd];
-        while (m) {
-          int k = wd * 64 + __builtin_ctzll(m);
-          m &= m - 1;
-          ShapeP q;
-          shape_head(shape_word(a, s_scene, t.b, k, lane), q);
-          float Av[9], ov[3];
-          load_shape_vgpr(a, s_scene, t.b, k, Av, ov);
-          trace_shape_p<P, false>(q.kind, Av, ov, k, d, best, tmin, nullptr);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) s_best_wave[p][lane] = (col_ok && p < t.nrows) ? best[p] : -1;
-    }
+    if (MULTI && s0 != smp_lo) settle(s0);
     RRT_STAMP(3);
     // walk the candidate shapes (one iteration for single-candidate tiles: the adjoint itself tests the hit)
     int wd = 0;
