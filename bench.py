@@ -60,6 +60,8 @@ def parse():
                          "c3: match_mirror scene (2 spheres + square) 1024^2, A=4; c5: 256 orbit scenes of 64^2, A=4")
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline band (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--equal-bands", action="store_true",
+                    help="N > 1, strong scaling: equal row counts per rank instead of bands of equal estimated cost")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce / barrier path even at world size 1 (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -169,6 +171,57 @@ class Job(object):
                                    ctypes.c_void_p(base + 4 * (B * S * 12 + S * 7)), self._p(self.ws), self.ws.numel(),
                                    self.stream)
         self.N.check(rc, "rrt_render_bwd")
+
+
+def probe_coverage(dev, args, probe=128):
+    """Per-row coverage (fraction of pixels that hit a shape) of a probe x probe rendering of the workload's view."""
+    pj = Job(dev, probe, args.spheres, 1, 0, probe, not args.no_cull, args.workload)
+    pj.fwd()
+    torch.cuda.synchronize()
+    return (pj.image[0].abs().sum(dim=-1) > 0).float().mean(dim=-1).cpu().numpy()
+
+
+def time_band(dev, args, full_rows, row0, rows, steps=60):
+    """us per step (forward + backward, no collective) of one row band, by the host clock around a synchronised loop"""
+    job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull, args.workload, full_rows=full_rows)
+    job.fwd()
+    job.grad.copy_(2.0 * (job.image - torch.flip(job.image, dims=[2])))
+    for _ in range(30):
+        job.fwd()
+        job.bwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.fwd()
+        job.bwd()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e6
+
+
+def balanced_bands_of(dev, args, full_rows, rank, world, dist, rounds=3):
+    """Row bands of equal cost for the strong-scaling run, found before anything is timed: a first cut from the coverage
+    of a 128-row probe render, then `rounds` measurements -- every rank times its own band, the times are all-gathered,
+    rrt.dist.rebalance_bands cuts again -- and the measured partition with the fastest slowest rank is kept.  Every
+    decision is taken on all-gathered numbers (rank 0's first cut is broadcast), so all ranks agree by construction
+    and run the same number of rounds."""
+    from rrt.dist import balanced_bands, rebalance_bands, row_cost_from_coverage
+    bands = balanced_bands(row_cost_from_coverage(probe_coverage(dev, args), full_rows), world)
+    t = torch.tensor(bands, dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0)
+    bands = [(int(a), int(b)) for a, b in t.cpu().tolist()]
+    best = None
+    for _ in range(rounds):
+        assert sum(b for _, b in bands) == full_rows and all(bands[r][0] + bands[r][1] == bands[r + 1][0] for r in range(world - 1))
+        mine = torch.tensor([time_band(dev, args, full_rows, *bands[rank])], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        times = [float(x.item()) for x in every]
+        if best is None or max(times) < best[0]:
+            best = (max(times), bands, times)
+        bands = rebalance_bands(bands, times)
+        if bands == best[1]:
+            break
+    return best[1], best[2]
 
 
 def cpu_baseline(size, spheres, aa, rows):
@@ -292,6 +345,12 @@ def main():
     # strong: the size x size image in `world` row bands; weak: `size` rows per rank of a (world*size) x size image
     full_rows = args.size * world if args.scaling == "weak" else args.size
     row0, rows = band(full_rows, rank, world)
+    all_bands = None
+    if use_dist and args.scaling == "strong" and args.workload == "c4" and not args.equal_bands:
+        # Strong scaling: a step is as slow as its slowest rank, and equal row counts differ by up to 20 % in time (N = 4:
+        # 33.4 ... 40.1 us).  Bands of equal cost are found here, before anything is timed (balanced_bands_of).
+        all_bands, band_times = balanced_bands_of(dev, args, full_rows, rank, world, dist)
+        row0, rows = all_bands[rank]
     job = Job(dev, args.size, args.spheres, args.aa, row0, rows, not args.no_cull, args.workload, full_rows=full_rows)
     args.spheres = job.S
 
@@ -403,8 +462,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"c4": "%d random spheres (seed 0), %dx%d, antialias_samples=%d, Phong+specular, "
-                                          "root camera, dense upstream grad; %d row band(s) of %d rows, one per GPU"
-                                          % (args.spheres, full_rows, args.size, args.aa, world, rows),
+                                          "root camera, dense upstream grad; %d row band(s), one per GPU: %s"
+                                          % (args.spheres, full_rows, args.size, args.aa, world,
+                                             ("of equal measured cost (probe render + 3 timed rounds before the run), rows " + "/".join(str(b) for _, b in all_bands))
+                                             if all_bands else "of %d rows" % rows),
                                     "c2": "config 2: 1 sphere Phong, 512x512, antialias_samples=1",
                                     "c3": "config 3: match_mirror.py scene (2 spheres + square), 1024x1024, "
                                           "antialias_samples=4, hash jitter",

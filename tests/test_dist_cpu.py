@@ -67,6 +67,61 @@ def test_band_partition_covers_rows_exactly():
             assert max(s[1] for s in spans) - min(s[1] for s in spans) <= 1
 
 
+def test_balanced_bands_partition():
+    """bands of equal estimated cost (strong scaling, bench.py's default for N > 1): contiguous, cover every row once,
+    boundaries on the tile height, nobody without rows while rows last, equal cost where the rows allow it; degenerate
+    inputs fall back to equal row counts"""
+    from rrt.dist import balanced_bands, band, row_cost_from_coverage
+    rs = np.random.RandomState(0)
+    for n, world in ((4096, 8), (4096, 3), (1000, 4), (130, 6), (64, 8)):
+        cov = np.clip(rs.rand(97) * (rs.rand(97) < 0.4), 0, 1)            # a probe of another height than the image
+        cost = row_cost_from_coverage(cov, n)
+        assert cost.shape == (n,) and (cost >= 1.0).all()
+        bands = balanced_bands(cost, world)
+        assert len(bands) == world and bands[0][0] == 0 and sum(b for _, b in bands) == n
+        for r in range(world - 1):
+            assert bands[r][0] + bands[r][1] == bands[r + 1][0] and bands[r + 1][0] % 4 == 0
+        assert all(b >= 1 for _, b in bands)
+        share = np.array([cost[a:a + b].sum() for a, b in bands]) / cost.sum() * world
+        if n >= 1000:
+            assert np.abs(share - 1.0).max() < 0.05
+    # a heavy lower half: the cut moves up
+    (a0, r0), (a1, r1) = balanced_bands(np.r_[np.ones(512), 3 * np.ones(512)], 2)
+    assert (a0, r0 + r1) == (0, 1024) and r0 > 640
+    # degenerate: fewer rows than ranks x tile height, zero or non-finite costs, one rank, no rows
+    assert balanced_bands(np.ones(7), 8) == [band(7, r, 8) for r in range(8)]
+    assert balanced_bands(np.zeros(64), 4) == [band(64, r, 4) for r in range(4)]
+    assert balanced_bands(np.full(64, np.nan), 4) == [band(64, r, 4) for r in range(4)]
+    assert balanced_bands(np.ones(64), 1) == [(0, 64)]
+    assert balanced_bands([], 3) == [(0, 0)] * 3
+
+
+def test_rebalance_bands_moves_rows_off_the_slow_rank():
+    """measured-cost balancing (bench.py --gpus N, before the timed region): a rank slower than the others gives rows
+    away, the partition stays exact, equal times change nothing much, and iterating on a synthetic cost converges"""
+    from rrt.dist import band, rebalance_bands
+    bands = [band(4096, r, 4) for r in range(4)]
+    new = rebalance_bands(bands, [33.9, 40.1, 33.7, 33.4])
+    assert sum(b for _, b in new) == 4096 and new[0][0] == 0
+    for r in range(3):
+        assert new[r][0] + new[r][1] == new[r + 1][0] and new[r + 1][0] % 4 == 0
+    assert new[1][1] < 1024 and all(new[r][1] > 1024 for r in (0, 2, 3))
+    same = rebalance_bands(bands, [35.0, 35.0, 35.0, 35.0])
+    assert max(abs(b - 1024) for _, b in same) <= 4
+    # a hidden per-row cost (a heavy stripe) + a fixed cost per rank: three rounds bring the slowest rank near the mean
+    true = np.ones(4096)
+    true[1200:1900] = 4.0
+
+    def measure(bs):
+        return [24.0 + 50.0 * true[a:a + b].sum() / true.sum() for a, b in bs]
+    t = measure(bands)
+    first = max(t) - min(t)
+    for _ in range(3):
+        bands = rebalance_bands(bands, t)
+        t = measure(bands)
+    assert max(t) - min(t) < 0.2 * first
+
+
 def test_two_rank_sharding_reproduces_single_process(tmp_path):
     import rrt_oracle as O
     from rrt import synthetic

@@ -17,13 +17,15 @@ sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import bench  # noqa: E402
-from rrt.dist import band  # noqa: E402
+from rrt.dist import band, balanced_bands, rebalance_bands, row_cost_from_coverage  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--spheres", type=int, default=32)
 ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--balanced", action="store_true", help="bands of equal estimated cost (bench.py's default for N > 1) instead of equal rows")
 args = ap.parse_args()
+args.no_cull, args.workload, args.aa = False, "c4", 1
 dev = torch.device("cuda:0")
 
 
@@ -50,10 +52,23 @@ def time_band(row0, rows):
 
 
 base = None
+cost = row_cost_from_coverage(bench.probe_coverage(dev, args), args.size) if args.balanced else None
 for n in (1, 2, 4, 8):
     per_rank = []
+    bands = balanced_bands(cost, n) if args.balanced else [band(args.size, r, n) for r in range(n)]
+    if args.balanced and n > 1:
+        # bench.py's procedure (balanced_bands_of), with this one GPU standing in for every rank in turn
+        best = None
+        for _ in range(3):
+            times = [bench.time_band(dev, args, args.size, *bands[r]) for r in range(n)]
+            if best is None or max(times) < best[0]:
+                best = (max(times), bands)
+            bands = rebalance_bands(bands, times)
+            if bands == best[1]:
+                break
+        bands = best[1]
     for r in range(n):
-        row0, rows = band(args.size, r, n)
+        row0, rows = bands[r]
         step, tf, tb = time_band(row0, rows)
         per_rank.append({"rank": r, "rows": rows, "step_us": round(step, 1), "fwd_call_us": round(tf, 1), "bwd_call_us": round(tb, 1)})
     slow = max(p["step_us"] for p in per_rank)
