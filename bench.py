@@ -198,21 +198,21 @@ def time_band(dev, args, full_rows, row0, rows, steps=60):
     return (time.perf_counter() - t0) / steps * 1e6
 
 
-def balanced_bands_of(dev, args, full_rows, rank, world, dist, rounds=3):
+def balanced_bands_of(dev, args, full_rows, rank, world, dist, rounds=3, probe=probe_coverage, timer=time_band):
     """Row bands of equal cost for the strong-scaling run, found before anything is timed: a first cut from the coverage
     of a 128-row probe render, then `rounds` measurements -- every rank times its own band, the times are all-gathered,
     rrt.dist.rebalance_bands cuts again -- and the measured partition with the fastest slowest rank is kept.  Every
     decision is taken on all-gathered numbers (rank 0's first cut is broadcast), so all ranks agree by construction
-    and run the same number of rounds."""
+    and run the same number of rounds.  (`probe` / `timer`: the CPU test of this choreography injects synthetic ones.)"""
     from rrt.dist import balanced_bands, rebalance_bands, row_cost_from_coverage
-    bands = balanced_bands(row_cost_from_coverage(probe_coverage(dev, args), full_rows), world)
+    bands = balanced_bands(row_cost_from_coverage(probe(dev, args), full_rows), world)
     t = torch.tensor(bands, dtype=torch.int64, device=dev)
     dist.broadcast(t, src=0)
     bands = [(int(a), int(b)) for a, b in t.cpu().tolist()]
     best = None
     for _ in range(rounds):
         assert sum(b for _, b in bands) == full_rows and all(bands[r][0] + bands[r][1] == bands[r + 1][0] for r in range(world - 1))
-        mine = torch.tensor([time_band(dev, args, full_rows, *bands[rank])], dtype=torch.float64, device=dev)
+        mine = torch.tensor([timer(dev, args, full_rows, *bands[rank])], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         times = [float(x.item()) for x in every]

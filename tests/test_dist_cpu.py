@@ -122,6 +122,48 @@ def test_rebalance_bands_moves_rows_off_the_slow_rank():
     assert max(t) - min(t) < 0.2 * first
 
 
+def _balance_worker(rank, world, port, out_dir):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (repo, os.path.join(repo, "reversible-raytracer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    true = np.ones(1024)
+    true[300:520] = 5.0                                # rows that cost five times the others (and show no extra coverage)
+
+    def probe(dev, args):
+        # rank 1 sees a last-bit-different probe: the first cut must still be rank 0's on every rank
+        return np.full(64, 0.25) + (1e-7 if rank == 1 else 0.0) * np.arange(64)
+
+    def timer(dev, args, full_rows, row0, rows):
+        return 24.0 + 60.0 * true[row0:row0 + rows].sum() / true.sum()
+    bands, times = bench.balanced_bands_of(torch.device("cpu"), None, 1024, rank, world, dist, probe=probe, timer=timer)
+    np.save(os.path.join(out_dir, "bands_%d.npy" % rank), np.array(bands))
+    np.save(os.path.join(out_dir, "times_%d.npy" % rank), np.array(times))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_band_balancing_choreography(tmp_path):
+    """bench.py's search for bands of equal measured cost, over gloo at world size 3 with a synthetic probe and timer:
+    every rank ends with the same exact partition (rank 0's first cut is broadcast, later cuts come from all-gathered
+    times), the collectives line up (no hang), and the slowest rank is faster than with equal row counts"""
+    port = _free_port()
+    mp.spawn(_balance_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    b = [np.load(tmp_path / ("bands_%d.npy" % r)) for r in range(3)]
+    t = [np.load(tmp_path / ("times_%d.npy" % r)) for r in range(3)]
+    assert np.array_equal(b[0], b[1]) and np.array_equal(b[0], b[2]) and np.array_equal(t[0], t[1]) and np.array_equal(t[0], t[2])
+    assert b[0][0, 0] == 0 and b[0][:, 1].sum() == 1024 and (b[0][:-1, 0] + b[0][:-1, 1] == b[0][1:, 0]).all()
+    true = np.ones(1024)
+    true[300:520] = 5.0
+    equal = max(24.0 + 60.0 * true[r * 1024 // 3:(r + 1) * 1024 // 3].sum() / true.sum() for r in range(3))
+    assert t[0].max() < equal - 5.0
+
+
 def test_two_rank_sharding_reproduces_single_process(tmp_path):
     import rrt_oracle as O
     from rrt import synthetic
